@@ -1,0 +1,91 @@
+"""CPU known-answer tests that need no reference run."""
+import math
+
+import torch
+
+from oracle.leaves import Attention, AlphaBlender
+from oracle.models import ControlNetModel, UNetSpatioTemporalConditionModel
+from oracle.scheduler import EulerDiscreteScheduler, denoise_loop
+from this_and_that_vdm_amd.utils.synthetic import fill_parameters_, synthetic_inputs
+
+SIGMAS = [700, 545.7292, 421.5691, 322.4537, 244.0231, 182.5471, 134.8544, 98.26714, 70.54084, 49.80979, 34.53674,
+          23.46751, 15.58997, 10.09713, 6.354266, 3.869697, 2.269116, 1.273177, 0.678146, 0.3393781, 0.1574046,
+          0.06639908, 0.02480258, 0.007882495, 0.002, 0.0]
+TIMESTEPS = [1.63777, 1.575531, 1.510996, 1.44399, 1.374316, 1.301752, 1.226049, 1.146922, 1.064048, 0.977053,
+             0.885506, 0.788904, 0.686657, 0.578063, 0.462282, 0.338294, 0.204848, 0.060379, -0.097098, -0.27016,
+             -0.462234, -0.678018, -0.924202, -1.210778, -1.553652]
+
+
+def test_karras_schedule_table():
+    s = EulerDiscreteScheduler()
+    s.set_timesteps(25)
+    torch.testing.assert_close(s.sigmas, torch.tensor(SIGMAS), rtol=2e-6, atol=1e-7)
+    torch.testing.assert_close(s.timesteps, torch.tensor(TIMESTEPS), rtol=1e-5, atol=2e-6)
+    assert abs(float(s.init_noise_sigma) - 700.000732) < 1e-3
+
+
+def test_euler_step_matches_closed_form():
+    s = EulerDiscreteScheduler()
+    s.set_timesteps(25)
+    x = torch.randn(1, 2, 4, 3, 3, generator=torch.Generator().manual_seed(1)) * 700
+    v = torch.randn(1, 2, 4, 3, 3, generator=torch.Generator().manual_seed(2))
+    t = s.timesteps[0]
+    xin = s.scale_model_input(x, t)
+    torch.testing.assert_close(xin, x / math.sqrt(700.0 ** 2 + 1))
+    out = s.step(v, t, x)
+    sg, sn = 700.0, SIGMAS[1]
+    x0 = v * (-sg / math.sqrt(sg * sg + 1)) + x / (sg * sg + 1)
+    torch.testing.assert_close(out, x + (x - x0) / sg * (sn - sg), rtol=1e-5, atol=1e-4)
+
+
+def test_zero_context_cross_attention_returns_bias():
+    a = Attention(query_dim=32, cross_attention_dim=16, heads=2, dim_head=16)
+    x = torch.randn(3, 5, 32)
+    out = a(x, encoder_hidden_states=torch.zeros(3, 4, 16))
+    torch.testing.assert_close(out, a.to_out[0].bias.expand_as(out))
+
+
+def test_alpha_blender_video_alpha():
+    b = AlphaBlender(0.5)
+    ind = torch.zeros(2, 3)
+    assert abs(float(b.get_alpha(ind, 3).flatten()[0]) - 0.6224593) < 1e-6
+
+
+def test_q3_time_context_pairing():
+    """Appendix D Q3: queries flatten (B,hw), contexts flatten (hw,B)."""
+    b, hw = 2, 4
+    q_rows = torch.arange(b).repeat_interleave(hw)
+    ctx_rows = torch.arange(b)[None].expand(hw, b).reshape(-1)
+    assert q_rows.tolist() == [0, 0, 0, 0, 1, 1, 1, 1] and ctx_rows.tolist() == [0, 1, 0, 1, 0, 1, 0, 1]
+
+
+@torch.no_grad()
+def test_zero_controlnet_gives_zero_residuals_and_vgl_equals_vl():
+    kw = dict(block_out_channels=(32, 64, 64, 64), num_attention_heads=(1, 1, 2, 2), cross_attention_dim=32)
+    unet = UNetSpatioTemporalConditionModel(num_frames=2, **kw).eval()
+    cn = ControlNetModel(**kw).eval()           # zero-init conv_in_concat and zero-convs (controlnet:203-205,254-297)
+    inp = synthetic_inputs(2, 2, 8, 8, ctx_tokens=3, ctx_dim=32)
+    x = torch.cat([torch.cat([inp["latents"]] * 2) / 700.0, inp["image_latents"]], dim=2)
+    cond = torch.randn(4, 4, 8, 8)
+    down, mid = cn(x, 1.0, inp["encoder_hidden_states"], inp["added_time_ids"], controlnet_cond=cond)
+    assert all(float(d.abs().max()) == 0.0 for d in down) and float(mid.abs().max()) == 0.0
+    a = unet(x, 1.0, inp["encoder_hidden_states"], inp["added_time_ids"])
+    b = unet(x, 1.0, inp["encoder_hidden_states"], inp["added_time_ids"],
+             down_block_additional_residuals=down, mid_block_additional_residual=mid)
+    torch.testing.assert_close(a, b, rtol=0, atol=0)
+
+
+@torch.no_grad()
+def test_denoise_loop_runs_and_is_deterministic():
+    kw = dict(block_out_channels=(32, 64, 64, 64), num_attention_heads=(1, 1, 2, 2), cross_attention_dim=32)
+    unet = UNetSpatioTemporalConditionModel(num_frames=2, **kw).eval()
+    cn = ControlNetModel(**kw).eval()
+    fill_parameters_(unet, "unet.")
+    fill_parameters_(cn, "controlnet.")
+    inp = synthetic_inputs(2, 2, 8, 8, ctx_tokens=3, ctx_dim=32)
+    args = (inp["latents"], inp["image_latents"], inp["encoder_hidden_states"], inp["added_time_ids"],
+            inp["gesture_latents"], inp["guidance_scale"])
+    a = denoise_loop(unet, cn, EulerDiscreteScheduler(), *args, num_inference_steps=3)
+    b = denoise_loop(unet, cn, EulerDiscreteScheduler(), *args, num_inference_steps=3)
+    assert a.shape == (1, 2, 4, 8, 8) and torch.isfinite(a).all()
+    torch.testing.assert_close(a, b, rtol=0, atol=0)
