@@ -1,0 +1,177 @@
+/*
+ * ttvdm.h -- C ABI of libttvdm.so: the MI355X (gfx950) kernels behind the SVD denoise hot path
+ * of Kiteretsu77/This_and_That_VDM.
+ *
+ * The reference has NO native boundary for this path: it is eager PyTorch calling stock
+ * Conv2d/Conv3d/Linear/GroupNorm/LayerNorm/SDPA through diffusers==0.25.1.  The
+ * entry points below are therefore the operators that path lowers to; each cites
+ * the reference site(s) whose work it replaces.  Citations are relative to /root/reference.
+ *
+ * Conventions
+ *   - plain C: pointers + sizes only.  Every pointer is a DEVICE pointer unless marked host.
+ *   - no ownership transfer, no allocation, no host sync inside: stream-ordered and stateless,
+ *     hence safe to capture in a hipGraph and thread-safe per stream.
+ *   - return 0 on success, a negative TT_E* code otherwise (never throws).
+ *   - activations are token-major ("NHWC"): [frames*batch, h*w, C], C contiguous.
+ *   - `dtype` selects the storage type of activations/weights: TT_BF16 or TT_F16; all
+ *     accumulation, norm statistics, softmax and small vectors (bias, FiLM rows) are fp32.
+ */
+#ifndef TTVDM_H
+#define TTVDM_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef void* tt_stream_t; /* hipStream_t */
+
+enum { TT_BF16 = 0, TT_F16 = 1 };
+enum { TT_OK = 0, TT_EINVAL = -1, TT_EUNSUPPORTED = -2, TT_ELAUNCH = -3 };
+
+/* library/ABI version and target arch string ("gfx950"). */
+int tt_abi_version(void);
+const char* tt_target_arch(void);
+/* text of the last error on the calling thread (host pointer, valid until the next call). */
+const char* tt_last_error(void);
+
+/* ------------------------------------------------------------------------------------------------
+ * tt_gemm: out = epilogue( gather(A) x W^T ).  One kernel family for every dense contraction:
+ *   mode 0  Linear            nn.Linear sites: transformer_temporal.py:326,373 (proj_in/out) and the
+ *                             diffusers Attention/FeedForward linears built at :240-261; 1x1 convs:
+ *                             ResnetBlock2D.conv_shortcut, temporal_controlnet.py:614-622 zero-convs.
+ *   mode 1  Conv2d 3x3 pad 1  ResnetBlock2D.conv1/conv2 (unet_3d_blocks.py:2094 etc.),
+ *                             Downsample2D stride 2 (:2117-2123), Upsample2D nearest x2 + conv
+ *                             (:2223,2332; the upsample is an index map, never materialised),
+ *                             conv_in / conv_in_concat / conv_out
+ *                             (unet_spatio_temporal_condition.py:455,528; temporal_controlnet.py:580).
+ *   mode 2  Conv3d (3,1,1)    TemporalResnetBlock.conv1/conv2 (diffusers; reached from
+ *                             unet_3d_blocks.py:1891-2316): 3 taps along the frame axis.
+ * W is [n, taps*(k0+k1)] row-major with k index (tap, source, channel); two sources implement
+ * torch.cat([h, skip], dim=1) (unet_3d_blocks.py:2242,2352) without a concat buffer.
+ * Epilogue, in this order (every term optional):
+ *   v = (acc + bias[n]) * acc_scale + rowvec[m / rowvec_rows][n]
+ *   geglu: v = v_value * gelu_erf(v_gate)      (W rows pre-interleaved in 16-row groups: 8 value, 8 gate)
+ *   v += residual[m][n];  v = alpha*blend[m][n] + (1-alpha)*v   (AlphaBlender, video branch)
+ * ---------------------------------------------------------------------------------------------- */
+typedef struct TtGemmArgs {
+  const void* a0; const void* a1;      /* activation sources; a1 NULL if k1 == 0 */
+  int32_t k0, k1;                      /* channels per tap taken from a0 / a1 (multiples of 8) */
+  int64_t lda0, lda1;                  /* row strides, elements */
+  const void* w; int64_t ldw;          /* [n, taps*(k0+k1)] */
+  int32_t m, n;                        /* n multiple of 4 */
+  int32_t mode;                        /* 0 linear, 1 conv3x3, 2 tconv3 */
+  int32_t nimg, hin, win, hout, wout, stride, upsample;   /* mode 1 (hin/win = stored input size) */
+  int32_t frames, hw;                  /* mode 2: row = (b*frames + f)*hw + p */
+  const float* bias;
+  float acc_scale;
+  const float* rowvec; int32_t rowvec_rows; int64_t ld_rowvec;
+  int32_t geglu;
+  const void* residual; int64_t ld_res;
+  const void* blend; int64_t ld_blend; float alpha;
+  void* out; int64_t ldo; int32_t out_f32;
+  int32_t out_col_hw, out_col_hwp;     /* if hw>0: column c -> (c/hw)*hwp + c%hw (padded V^T sequences) */
+  int32_t dtype;
+} TtGemmArgs;
+int tt_gemm(const TtGemmArgs* args, tt_stream_t stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * tt_attention: softmax(Q K^T / sqrt(d)) V with online softmax on MFMA tiles; replaces
+ * F.scaled_dot_product_attention inside diffusers AttnProcessor2_0 for
+ *   mask 0  spatial self-attention            (BasicTransformerBlock.attn1; transformer_temporal.py:353)
+ *   mask 1  spatial cross-attention, S<=pad   (attn2; context of batch n/frames)
+ *   mask 2  temporal cross-attention          (TemporalBasicTransformerBlock.attn2, :361-365) with the
+ *           reference's (hw,B)-flattened context pairing reproduced: query (b,p) sees context
+ *           (b*hw + p) % ctx_batches  (transformer_temporal.py:316-319).
+ * q [nseq*lq, ldq] (+ head*d), k [rows, ldk] (+ head*d), vt = V transposed [heads*d, ldvt].
+ * ---------------------------------------------------------------------------------------------- */
+typedef struct TtAttnArgs {
+  const void* q; int64_t ldq;
+  const void* k; int64_t ldk;
+  const void* vt; int64_t ldvt;
+  void* out; int64_t ldo;
+  int32_t nseq, lq, heads, head_dim;   /* head_dim 64 or 128 */
+  int32_t mask;                        /* 0,1,2 as above */
+  int32_t lk;                          /* valid keys per sequence/context */
+  int32_t k_seq_stride, v_seq_stride;  /* rows of k / columns of vt per sequence (mask 0) or per context (1,2) */
+  int32_t frames, ctx_batches;         /* masks 1,2 */
+  int32_t dtype;
+} TtAttnArgs;
+int tt_attention(const TtAttnArgs* args, tt_stream_t stream);
+
+/* temporal self-attention over the frame axis (seq = frames <= 32), one 16/32-lane group per
+ * (batch, pixel, head); replaces TemporalBasicTransformerBlock.attn1 incl. its two
+ * [(B F),hw,C] <-> [(B hw),F,C] permute copies (diffusers; reached from transformer_temporal.py:361).
+ * qkv [batch*frames*hw, ldqkv] holds Q | K | V at column offsets 0, C, 2C. */
+int tt_temporal_attention(const void* qkv, int64_t ldqkv, void* out, int64_t ldo, int32_t batch, int32_t frames,
+                          int32_t hw, int32_t heads, int32_t head_dim, int32_t dtype, tt_stream_t stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * GroupNorm(32 groups) split in statistics -> affine (+SiLU); nn.GroupNorm sites: ResnetBlock2D /
+ * TemporalResnetBlock norm1/norm2, transformer_temporal.py:234,323, unet...:244,526.
+ * `frames_per_group` = 1 for per-image statistics, = F for the temporal block (stats over F*h*w).
+ * Two sources = virtual channel concat.  ws must hold tt_groupnorm_ws_bytes().
+ * tt_groupnorm_stats writes per-(image, channel) scale/shift fp32 [nimg, C] each:
+ *     y = x*scale + shift  ==  (x-mean)*rstd*gamma + beta
+ * ---------------------------------------------------------------------------------------------- */
+size_t tt_groupnorm_ws_bytes(int32_t nimg, int32_t hw, int32_t c);
+int tt_groupnorm_stats(const void* x0, int32_t c0, const void* x1, int32_t c1, int32_t nimg, int32_t hw,
+                       int32_t frames_per_group, const float* gamma, const float* beta, float eps,
+                       float* scale, float* shift, void* ws, size_t ws_bytes, int32_t dtype, tt_stream_t stream);
+/* y[n,p,0:c0+c1] = act(x*scale+shift), act = SiLU if silu else identity; y has row stride ldy (>= c0+c1,
+ * extra columns untouched). */
+int tt_groupnorm_apply(const void* x0, int32_t c0, const void* x1, int32_t c1, int32_t nimg, int32_t hw,
+                       const float* scale, const float* shift, int32_t silu, void* y, int64_t ldy,
+                       int32_t dtype, tt_stream_t stream);
+
+/* LayerNorm over the last dim (eps, affine); nn.LayerNorm inside Basic/TemporalBasicTransformerBlock.
+ * Optional fused frame-position embedding (transformer_temporal.py:358-359): when rowvec != NULL,
+ * x' = x + rowvec[(row / rows_per_vec) % nvec] is written to xsum_out and normalised. */
+int tt_layernorm(const void* x, int64_t ldx, int32_t rows, int32_t c, const float* gamma, const float* beta,
+                 float eps, const float* rowvec, int32_t rows_per_vec, int32_t nvec, void* xsum_out,
+                 void* y, int64_t ldy, int32_t dtype, tt_stream_t stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * small dense layers on <=32 rows, fp32 activations (time / add / FiLM / frame-position MLPs:
+ * unet...:416-432, ResnetBlock2D.time_emb_proj, transformer_temporal.py:338):
+ *   y[r][n] = act_out( sum_k act_in(x[r][k]) * W[n][k] + bias[n] ),  act: 0 none, 1 SiLU.
+ * W is `dtype`, x/y/bias fp32.  accumulate != 0 adds into y.
+ * ---------------------------------------------------------------------------------------------- */
+int tt_small_linear(const float* x, int64_t ldx, int32_t rows, int32_t k, const void* w, int64_t ldw, int32_t n,
+                    const float* bias, int32_t act_in, int32_t act_out, int32_t accumulate, float* y, int64_t ldy,
+                    int32_t dtype, tt_stream_t stream);
+/* diffusers Timesteps(dim, flip_sin_to_cos=True, shift=0): out[r] = [cos(t_r*f_i) | sin(t_r*f_i)], fp32.
+ * `t` device fp32 [rows]. */
+int tt_timestep_embedding(const float* t, int32_t rows, int32_t dim, float* out, int64_t ldo, tt_stream_t stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * denoise-loop glue (pipeline_stable_video_diffusion_controlnet.py:630-635,704-709):
+ * tt_prep_model_input: x[b,f,p,0:4] = latents[f,:,p] * c_in (CFG: same latents for every b),
+ *   x[...,4:8] = image_latents[b,f,:,p], x[...,8:12] = cond[f,:,p] (if cond), rest of cpad zero.
+ *   latents/image_latents/cond are fp32 NCHW-per-frame as the pipeline holds them.
+ * tt_cfg_euler_step: eps[b,f,p,0:4] fp32 token-major (conv_out) ->
+ *   v = u + g_f*(c-u);  x0 = v*(-s/sqrt(s^2+1)) + x/(s^2+1);  x += (x-x0)/s*(s_next-s)   (in place, fp32)
+ * sigma scalars live on the device (sigmas[step], sigmas[step+1]) so a captured graph can be replayed
+ * for every step.
+ * ---------------------------------------------------------------------------------------------- */
+int tt_prep_model_input(const float* latents, const float* image_latents, const float* cond, const float* sigmas,
+                        int32_t step, int32_t batch, int32_t frames, int32_t h, int32_t w, int32_t cpad,
+                        void* x, int32_t dtype, tt_stream_t stream);
+int tt_cfg_euler_step(const float* eps, int32_t ld_eps, float* latents, const float* guidance, const float* sigmas,
+                      int32_t step, int32_t batch, int32_t frames, int32_t h, int32_t w, tt_stream_t stream);
+
+/* layout plumbing at the drop-in boundary: NCHW (any float dtype code below) <-> token-major.
+ * src_kind/dst_kind: 0 = dtype (bf16/f16), 1 = fp32. */
+int tt_nchw_to_tokens(const void* src, int32_t src_f32, int32_t nimg, int32_t c, int32_t hw, void* dst, int64_t ld_dst,
+                      int32_t dtype, tt_stream_t stream);
+int tt_tokens_to_nchw(const void* src, int32_t src_f32, int64_t ld_src, int32_t nimg, int32_t c, int32_t hw, void* dst,
+                      int32_t dst_f32, int32_t dtype, tt_stream_t stream);
+/* y = a + b*scale (dtype, elementwise, n multiple of 8): ControlNet residual add, unet...:485-491,501-502. */
+int tt_add_scaled(const void* a, const void* b, float scale, void* y, int64_t n, int32_t dtype, tt_stream_t stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* TTVDM_H */

@@ -1,0 +1,300 @@
+"""GPU: every libttvdm kernel (called through the C ABI) against a plain PyTorch fp32 reference of the
+same op evaluated on the SAME low-precision inputs.  Tolerances (stated per test): outputs are rounded
+to fp16 (2^-11 rel) / bf16 (2^-8 rel) on store, accumulation is fp32."""
+import math
+
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+
+DTYPES = [torch.float16, torch.bfloat16]
+TOL = {torch.float16: dict(rtol=2e-3, atol=2e-3), torch.bfloat16: dict(rtol=1.6e-2, atol=1.6e-2)}
+
+
+@pytest.fixture(scope="module")
+def ops():
+    if not torch.cuda.is_available():
+        pytest.skip("needs a GPU")
+    from this_and_that_vdm_amd import ops as o
+    return o
+
+
+def rnd(*shape, dtype, seed, scale=1.0):
+    g = torch.Generator().manual_seed(seed)
+    return (torch.randn(*shape, generator=g) * scale).to(dtype)
+
+
+def close(got, ref, dtype, scale=1.0):
+    tol = TOL[dtype]
+    torch.testing.assert_close(got.float().cpu(), ref.float(), rtol=tol["rtol"], atol=tol["atol"] * scale)
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("m,n,k", [(300, 72, 40), (1000, 320, 640), (129, 132, 64), (4096, 256, 1280)])
+def test_gemm_linear_full_epilogue(ops, dtype, m, n, k):
+    a, w = rnd(m, k, dtype=dtype, seed=1), rnd(n, k, dtype=dtype, seed=2, scale=k ** -0.5)
+    bias = rnd(n, dtype=torch.float32, seed=3)
+    rows_per = 50
+    rowvec = rnd((m + rows_per - 1) // rows_per, n, dtype=torch.float32, seed=4)
+    res, bl = rnd(m, n, dtype=dtype, seed=5), rnd(m, n, dtype=dtype, seed=6)
+    out = ops.gemm(a.cuda(), w.cuda(), bias=bias.cuda(), acc_scale=0.75, rowvec=rowvec.cuda(), rowvec_rows=rows_per,
+                   residual=res.cuda(), blend=bl.cuda(), alpha=0.3)
+    ref = (a.float() @ w.float().T + bias) * 0.75 + rowvec.repeat_interleave(rows_per, 0)[:m] + res.float()
+    ref = 0.3 * bl.float() + 0.7 * ref
+    close(out, ref, dtype, scale=2.0)
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+def test_gemm_is_transpose_safe(ops, dtype):
+    """A = I with an asymmetric W: catches swapped row/col fragment maps (cdna guide rule 16)."""
+    n = 96
+    a = torch.eye(64, dtype=dtype)
+    w = (torch.arange(n * 64).reshape(n, 64) % 251 - 125).to(dtype) / 64
+    out = ops.gemm(a.cuda(), w.cuda())
+    torch.testing.assert_close(out.float().cpu(), w.float().T, rtol=0, atol=0)
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+def test_gemm_two_sources_and_f32_out(ops, dtype):
+    m, n, k0, k1 = 500, 64, 64, 40
+    a0, a1 = rnd(m, k0, dtype=dtype, seed=1), rnd(m, k1, dtype=dtype, seed=2)
+    w = rnd(n, k0 + k1, dtype=dtype, seed=3, scale=0.1)
+    out = ops.gemm(a0.cuda(), w.cuda(), a1=a1.cuda(), out_f32=True)
+    assert out.dtype == torch.float32
+    ref = torch.cat([a0, a1], 1).float() @ w.float().T
+    torch.testing.assert_close(out.cpu(), ref, rtol=1e-4, atol=1e-4)
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+def test_gemm_geglu(ops, dtype):
+    m, c = 260, 64
+    a = rnd(m, c, dtype=dtype, seed=1)
+    w = rnd(8 * c, c, dtype=dtype, seed=2, scale=c ** -0.5)        # nn.Linear(c, 8c): rows [value 4c | gate 4c]
+    b = rnd(8 * c, dtype=torch.float32, seed=3)
+    from this_and_that_vdm_amd.packing import pack_geglu
+    wp, bp = pack_geglu(w, b)
+    out = ops.gemm(a.cuda(), wp.cuda(), bias=bp.cuda(), geglu=True)
+    h = a.float() @ w.float().T + b
+    ref = h[:, :4 * c] * F.gelu(h[:, 4 * c:])
+    assert out.shape == (m, 4 * c)
+    close(out, ref, dtype)
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("stride,upsample", [(1, 0), (2, 0), (1, 1)])
+def test_gemm_conv3x3(ops, dtype, stride, upsample):
+    nimg, cin0, cin1, cout, h, w = 3, 32, 24, 40, 10, 14
+    x0, x1 = rnd(nimg, cin0, h, w, dtype=dtype, seed=1), rnd(nimg, cin1, h, w, dtype=dtype, seed=2)
+    wt = rnd(cout, cin0 + cin1, 3, 3, dtype=dtype, seed=3, scale=0.06)
+    bias = rnd(cout, dtype=torch.float32, seed=4)
+    from this_and_that_vdm_amd.packing import pack_conv3x3
+    wp = pack_conv3x3(wt)
+    xin = torch.cat([x0, x1], 1).float()
+    if upsample:
+        xin = F.interpolate(xin, scale_factor=2.0, mode="nearest")
+    ref = F.conv2d(xin, wt.float(), bias, stride=stride, padding=1)
+    ho, wo = ref.shape[-2:]
+    t0 = x0.permute(0, 2, 3, 1).reshape(-1, cin0).contiguous().cuda()
+    t1 = x1.permute(0, 2, 3, 1).reshape(-1, cin1).contiguous().cuda()
+    out = ops.gemm(t0, wp.cuda(), a1=t1, mode=1, conv=(nimg, h, w, ho, wo, stride, upsample), bias=bias.cuda())
+    close(out, ref.permute(0, 2, 3, 1).reshape(-1, cout), dtype)
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+def test_gemm_temporal_conv(ops, dtype):
+    b, f, hw, c = 2, 5, 12, 64
+    x = rnd(b, c, f, hw, 1, dtype=dtype, seed=1)
+    wt = rnd(c, c, 3, 1, 1, dtype=dtype, seed=2, scale=0.07)
+    bias = rnd(c, dtype=torch.float32, seed=3)
+    ref = F.conv3d(x.float(), wt.float(), bias, padding=(1, 0, 0))          # [b,c,f,hw,1]
+    from this_and_that_vdm_amd.packing import pack_tconv3
+    tok = x[..., 0].permute(0, 2, 3, 1).reshape(b * f * hw, c).contiguous().cuda()
+    out = ops.gemm(tok, pack_tconv3(wt).cuda(), mode=2, tconv=(f, hw), bias=bias.cuda())
+    close(out, ref[..., 0].permute(0, 2, 3, 1).reshape(b * f * hw, c), dtype)
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+def test_gemm_transposed_padded_output(ops, dtype):
+    """V^T projection: out[c, seq*hwp + p] with sequences padded 28 -> 32 columns."""
+    nseq, hw, hwp, c, k = 3, 28, 32, 64, 48
+    x, w = rnd(nseq * hw, k, dtype=dtype, seed=1), rnd(c, k, dtype=dtype, seed=2, scale=0.1)
+    out = torch.zeros(c, nseq * hwp, dtype=dtype, device="cuda")
+    ops.gemm(w.cuda(), x.cuda(), out=out, out_col_pad=(hw, hwp))
+    ref = (w.float() @ x.float().T).reshape(c, nseq, hw)
+    got = out.float().cpu().reshape(c, nseq, hwp)
+    close(got[:, :, :hw], ref, dtype)
+    assert float(got[:, :, hw:].abs().max()) == 0.0
+
+
+def _sdpa(q, k, v, heads):
+    n, lq, c = q.shape
+    d = c // heads
+    qh, kh, vh = [t.float().view(t.shape[0], -1, heads, d).transpose(1, 2) for t in (q, k, v)]
+    return F.scaled_dot_product_attention(qh, kh, vh).transpose(1, 2).reshape(n, lq, c)
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("l,heads,d", [(100, 2, 64), (256, 1, 64), (28, 2, 64), (200, 1, 128)])
+def test_attention_self(ops, dtype, l, heads, d):
+    nseq, c = 3, heads * d
+    q, k, v = (rnd(nseq, l, c, dtype=dtype, seed=s) for s in (1, 2, 3))
+    lp = (l + 7) // 8 * 8
+    vt = torch.zeros(c, nseq * lp, dtype=dtype)
+    vt.view(c, nseq, lp)[:, :, :l] = v.permute(2, 0, 1)
+    out = torch.empty(nseq * l, c, dtype=dtype, device="cuda")
+    ops.attention(q.reshape(-1, c).cuda(), k.reshape(-1, c).cuda(), vt.cuda(), out, nseq=nseq, lq=l, heads=heads, head_dim=d,
+                  mask=0, lk=l, k_seq_stride=l, v_seq_stride=lp)
+    close(out.view(nseq, l, c), _sdpa(q, k, v, heads), dtype)
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+def test_attention_softmax_rescale_branch(ops, dtype):
+    """one key in a LATER tile dominates a row: forces the online-softmax rescale (guide rule 26)."""
+    l, d = 192, 64
+    q, k, v = (rnd(1, l, d, dtype=dtype, seed=s) for s in (1, 2, 3))
+    k[0, 150] = (q[0, 7].float() * 4).to(dtype)
+    vt = v[0].T.contiguous()
+    out = torch.empty(l, d, dtype=dtype, device="cuda")
+    ops.attention(q[0].cuda(), k[0].cuda(), vt.cuda(), out, nseq=1, lq=l, heads=1, head_dim=d, mask=0, lk=l,
+                  k_seq_stride=l, v_seq_stride=l)
+    close(out[None], _sdpa(q, k, v, 1), dtype)
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("s", [1, 5, 78])
+def test_attention_cross_spatial_and_temporal(ops, dtype, s):
+    b, f, hw, heads, d = 2, 3, 40, 2, 64
+    c = heads * d
+    sp = (s + 7) // 8 * 8
+    q = rnd(b * f, hw, c, dtype=dtype, seed=1)
+    kc, vc = rnd(b, s, c, dtype=dtype, seed=2), rnd(b, s, c, dtype=dtype, seed=3)
+    kpad = torch.zeros(b, sp, c, dtype=dtype)
+    kpad[:, :s] = kc
+    vt = torch.zeros(c, b * sp, dtype=dtype)
+    vt.view(c, b, sp)[:, :, :s] = vc.permute(2, 0, 1)
+    qd, kd, vd = q.reshape(-1, c).cuda(), kpad.reshape(-1, c).cuda(), vt.cuda()
+    # spatial: frame n sees the context of batch n // f
+    out = torch.empty(b * f * hw, c, dtype=dtype, device="cuda")
+    ops.attention(qd, kd, vd, out, nseq=b * f, lq=hw, heads=heads, head_dim=d, mask=1, lk=s, k_seq_stride=sp,
+                  v_seq_stride=sp, frames=f, ctx_batches=b)
+    ref = _sdpa(q, kc.repeat_interleave(f, 0), vc.repeat_interleave(f, 0), heads)
+    close(out.view(b * f, hw, c), ref, dtype)
+    # temporal (reference quirk Q3): token (b, p) sees context (b*hw + p) % B
+    out2 = torch.empty_like(out)
+    ops.attention(qd, kd, vd, out2, nseq=b * f, lq=hw, heads=heads, head_dim=d, mask=2, lk=s, k_seq_stride=sp,
+                  v_seq_stride=sp, frames=f, ctx_batches=b)
+    sel = (torch.arange(b)[:, None] * hw + torch.arange(hw)[None]) % b                      # [b, hw]
+    qt = q.view(b, f, hw, c).permute(0, 2, 1, 3).reshape(b * hw, f, c)
+    ref2 = _sdpa(qt, kc[sel.reshape(-1)], vc[sel.reshape(-1)], heads)
+    ref2 = ref2.view(b, hw, f, c).permute(0, 2, 1, 3).reshape(b * f, hw, c)
+    close(out2.view(b * f, hw, c), ref2, dtype)
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("frames,heads,d", [(14, 3, 64), (4, 1, 64), (25, 2, 64), (3, 2, 128)])
+def test_temporal_self_attention(ops, dtype, frames, heads, d):
+    b, hw, c = 2, 19, heads * d
+    qkv = rnd(b * frames * hw, 3 * c, dtype=dtype, seed=1)
+    out = torch.empty(b * frames * hw, c, dtype=dtype, device="cuda")
+    ops.temporal_attention(qkv.cuda(), out, batch=b, frames=frames, hw=hw, heads=heads, head_dim=d)
+    t = qkv.view(b, frames, hw, 3, c).permute(3, 0, 2, 1, 4).reshape(3, b * hw, frames, c)
+    ref = _sdpa(t[0], t[1], t[2], heads).view(b, hw, frames, c).permute(0, 2, 1, 3).reshape(-1, c)
+    close(out, ref, dtype)
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("c0,c1,fpg", [(64, 0, 1), (64, 32, 1), (320, 0, 4), (640, 320, 1)])
+def test_groupnorm(ops, dtype, c0, c1, fpg):
+    nimg, h, w = 4, 9, 11
+    x0 = rnd(nimg, c0, h, w, dtype=dtype, seed=1, scale=3.0) + 1.5
+    x1 = rnd(nimg, c1, h, w, dtype=dtype, seed=2) if c1 else None
+    c = c0 + c1
+    gamma, beta = rnd(c, dtype=torch.float32, seed=3) + 1, rnd(c, dtype=torch.float32, seed=4)
+    xin = torch.cat([x0, x1], 1).float() if c1 else x0.float()
+    b = nimg // fpg
+    x5 = xin.view(b, fpg, c, h, w).permute(0, 2, 1, 3, 4)
+    ref = F.silu(F.group_norm(x5, 32, gamma, beta, eps=1e-5)).permute(0, 2, 1, 3, 4).reshape(nimg, c, h, w)
+    tok = lambda t: t.permute(0, 2, 3, 1).reshape(-1, t.shape[1]).contiguous().cuda()
+    t0, t1 = tok(x0), (tok(x1) if c1 else None)
+    sc, sh = ops.groupnorm_stats(t0, t1, nimg, h * w, fpg, gamma.cuda(), beta.cuda(), 1e-5)
+    y = ops.groupnorm_apply(t0, t1, nimg, h * w, sc, sh, True)
+    close(y, ref.permute(0, 2, 3, 1).reshape(-1, c), dtype, scale=2.0)
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("c", [64, 320, 1280])
+def test_layernorm_and_fused_frame_embedding(ops, dtype, c):
+    rows = 37 * 6
+    x = rnd(rows, c, dtype=dtype, seed=1, scale=2.0)
+    g, b = rnd(c, dtype=torch.float32, seed=2) + 1, rnd(c, dtype=torch.float32, seed=3)
+    y = ops.layernorm(x.cuda(), g.cuda(), b.cuda(), 1e-5)
+    close(y, F.layer_norm(x.float(), (c,), g, b, 1e-5), dtype, scale=2.0)
+    emb = rnd(3, c, dtype=torch.float32, seed=4)
+    xs, y2 = ops.layernorm(x.cuda(), g.cuda(), b.cuda(), 1e-5, rowvec=emb.cuda(), rows_per_vec=37, nvec=3)
+    xsum = x.float() + emb.repeat(2, 1).repeat_interleave(37, 0)
+    close(xs, xsum, dtype, scale=2.0)
+    close(y2, F.layer_norm(xsum, (c,), g, b, 1e-5), dtype, scale=2.0)
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+def test_small_linear_and_timestep_embedding(ops, dtype):
+    from oracle.leaves import get_timestep_embedding
+    t = torch.tensor([1.63777, -0.4622, 6.0, 200.0, 0.1])
+    emb = ops.timestep_embedding(t.cuda(), 320)
+    torch.testing.assert_close(emb.cpu(), get_timestep_embedding(t, 320, True, 0), rtol=1e-4, atol=2e-4)
+    x = rnd(3, 320, dtype=torch.float32, seed=1)
+    w, b = rnd(1280, 320, dtype=dtype, seed=2, scale=0.05), rnd(1280, dtype=torch.float32, seed=3)
+    y = ops.small_linear(x.cuda(), w.cuda(), b.cuda(), act_in=True, act_out=True)
+    ref = F.silu(F.silu(x) @ w.float().T + b)
+    torch.testing.assert_close(y.cpu(), ref, rtol=1e-4, atol=1e-4)
+    y2 = ops.small_linear(x.cuda(), w.cuda(), None, out=y.clone(), accumulate=True)
+    torch.testing.assert_close(y2.cpu(), ref + x @ w.float().T, rtol=1e-4, atol=1e-4)
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+def test_denoise_glue_matches_oracle_scheduler(ops, dtype):
+    from oracle.scheduler import EulerDiscreteScheduler
+    f, h, w = 5, 6, 7
+    s = EulerDiscreteScheduler()
+    s.set_timesteps(25)
+    lat = rnd(1, f, 4, h, w, dtype=torch.float32, seed=1, scale=300.0)
+    img = rnd(2, f, 4, h, w, dtype=torch.float32, seed=2)
+    cond = rnd(f, 4, h, w, dtype=torch.float32, seed=3)
+    step = 3
+    s._step_index = step
+    x = ops.prep_model_input(lat.cuda(), img.cuda(), cond.cuda(), s.sigmas.cuda(), step, 2, f, h, w, 64, dtype)
+    t = s.timesteps[step]
+    ref_in = torch.cat([s.scale_model_input(torch.cat([lat] * 2), t), img, torch.cat([cond, cond])[None].view(2, f, 4, h, w)], dim=2)
+    got = x.float().cpu().view(2, f, h, w, 64)
+    close(got[..., :12].permute(0, 1, 4, 2, 3), ref_in, dtype)
+    assert float(got[..., 12:].abs().max()) == 0.0
+    eps = rnd(2, f, 4, h, w, dtype=torch.float32, seed=4)
+    g = torch.linspace(1, 3, f)
+    u, c = eps.chunk(2)
+    ref = s.step(u + g.view(1, f, 1, 1, 1) * (c - u), t, lat)
+    eps_tok = eps.permute(0, 1, 3, 4, 2).reshape(-1, 4).contiguous().cuda()
+    lat_d = lat.clone().cuda()
+    ops.cfg_euler_step(eps_tok, lat_d, g.cuda(), s.sigmas.cuda(), step, 2, f, h, w)
+    torch.testing.assert_close(lat_d.cpu(), ref, rtol=1e-5, atol=1e-3)
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+def test_layout_plumbing(ops, dtype):
+    x = rnd(3, 40, 5, 7, dtype=torch.float32, seed=1)
+    tok = ops.nchw_to_tokens(x.cuda(), dtype, ld=64)
+    assert tok.shape == (3 * 35, 64)
+    close(tok[:, :40], x.permute(0, 2, 3, 1).reshape(-1, 40), dtype)
+    back = ops.tokens_to_nchw(tok, 3, 40, 5, 7, torch.float32)
+    close(back, x, dtype)
+    a, b = rnd(64, 40, dtype=dtype, seed=2), rnd(64, 40, dtype=dtype, seed=3)
+    close(ops.add_scaled(a.cuda(), b.cuda(), 0.5), a.float() + 0.5 * b.float(), dtype)
+
+
+def test_errors_are_loud(ops):
+    a = torch.zeros(8, 12, dtype=torch.float16, device="cuda")       # k not a multiple of 8
+    with pytest.raises(RuntimeError, match="tt_gemm"):
+        ops.gemm(a, torch.zeros(8, 12, dtype=torch.float16, device="cuda"))
+    with pytest.raises(RuntimeError, match="HIP device"):
+        ops.gemm(torch.zeros(8, 16, dtype=torch.float16), torch.zeros(8, 16, dtype=torch.float16))

@@ -1,0 +1,353 @@
+// tt_attention: flash-style attention on gfx950 MFMA; tt_temporal_attention: frame-axis attention.
+//
+// tt_attention -- per (q-block of 128 rows, head, sequence): 4 waves x 32 query rows.
+//   S^T = K Q^T  (v_mfma 32x32x16, K tile rows as the MFMA "A" operand, Q^T held in registers as "B"),
+//   so every lane owns ONE query column and 16 keys of each 32-key block: the softmax row reductions
+//   are in-register plus a single lane^32 exchange, and P (converted in-register) is already the "B"
+//   operand of  O^T += V^T P^T.  V is consumed TRANSPOSED from memory (vt = [heads*d, keys], written
+//   by the V projection GEMM with swapped operands), so both tiles are plain K-contiguous rows staged by
+//   the same LDS-DMA + swizzle as the GEMM.  K tile rows are permuted on the READ side (pi below) so
+//   that accumulator register r of a lane is key 16*(lane>>5)+r: P needs no data movement at all.
+//   Online softmax in fp32 with exp2; masked keys get -inf, running max starts at -1e30 (no NaN).
+#include "common.h"
+
+namespace {
+
+struct AttnP {
+  const char* q; long ldq;
+  const char* k; long ldk;
+  const char* vt; long ldvt;
+  char* out; long ldo;
+  int nseq, lq, heads;
+  int mask, lk, k_seq_stride, v_seq_stride, frames, ctx_batches;
+  int k_rows_total;     // rows of k that exist (for the zero-page predicate)
+  long vt_cols_total;   // columns of vt that exist
+  float scale_log2e;
+};
+
+constexpr int QB = 128;   // queries per block
+constexpr int KB = 64;    // keys per tile
+
+template <typename Tag, int D>
+__global__ __launch_bounds__(256) void attn_kernel(const AttnP p) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  constexpr int KCPR = D / 8;                 // 16-B chunks per K-tile row (row = key, D elements)
+  constexpr int K_BYTES = KB * D * 2;
+  constexpr int V_BYTES = D * KB * 2;         // rows = d (D rows), 64 keys = 128 B per row
+  constexpr int STAGE = K_BYTES + V_BYTES;
+  constexpr int KPT = (KB * KCPR) / 256;      // K chunks per thread
+  constexpr int VPT = (D * 8) / 256;          // Vt chunks per thread
+  constexpr int DS = D / 16, DB = D / 32;
+
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int l31 = lane & 31, hi = lane >> 5;
+  const int qblk = blockIdx.x, head = blockIdx.y, seq = blockIdx.z;
+  const char* zero = (const char*)tt_zero_page;
+
+  // ---- which keys does this sequence see
+  int kbase, vbase, ntiles;
+  if (p.mask == 0) { kbase = seq * p.k_seq_stride; vbase = seq * p.v_seq_stride; ntiles = (p.lk + KB - 1) / KB; }
+  else if (p.mask == 1) { const int b = seq / p.frames; kbase = b * p.k_seq_stride; vbase = b * p.v_seq_stride; ntiles = (p.lk + KB - 1) / KB; }
+  else { kbase = 0; vbase = 0; ntiles = (p.ctx_batches * p.k_seq_stride + KB - 1) / KB; }
+
+  // ---- Q^T fragments straight from global: lane (query l31) holds d = ds*16 + hi*8 .. +8
+  const int qrow = qblk * QB + wid * 32 + l31;
+  const bool qok = qrow < p.lq;
+  uint4 qf[DS];
+  {
+    const char* qp = p.q + (((long)seq * p.lq + (qok ? qrow : 0)) * p.ldq + head * D) * 2;
+#pragma unroll
+    for (int ds = 0; ds < DS; ++ds) qf[ds] = qok ? *(const uint4*)(qp + (ds * 16 + hi * 8) * 2) : make_uint4(0, 0, 0, 0);
+  }
+  // temporal-cross pairing (reference quirk Q3): the context this query may look at
+  int my_ctx = 0;
+  if (p.mask == 2) my_ctx = (int)((((long)(seq / p.frames)) * p.lq + (qok ? qrow : 0)) % p.ctx_batches);
+
+  auto stage = [&](int buf, int tile) {
+    const int j0 = tile * KB;
+    char* lk_ = smem + buf * STAGE + wid * 1024;
+    char* lv_ = smem + buf * STAGE + K_BYTES + wid * 1024;
+#pragma unroll
+    for (int i = 0; i < KPT; ++i) {
+      const int slot = i * 256 + tid;
+      const int r = slot / KCPR, c = (slot % KCPR) ^ tile_swz<KCPR>(r);
+      const long krow = (long)kbase + j0 + r;
+      const bool ok = krow < p.k_rows_total;
+      glds16(ok ? p.k + (krow * p.ldk + head * D + c * 8) * 2 : zero, lk_ + i * 4096);
+    }
+#pragma unroll
+    for (int i = 0; i < VPT; ++i) {
+      const int slot = i * 256 + tid;
+      const int r = slot >> 3, c = (slot & 7) ^ tile_swz<8>(r);
+      const long col = (long)vbase + j0 + c * 8;
+      const bool ok = col < p.vt_cols_total;
+      glds16(ok ? p.vt + ((long)(head * D + r) * p.ldvt + col) * 2 : zero, lv_ + i * 4096);
+    }
+  };
+
+  f32x16_t o[DB];
+#pragma unroll
+  for (int i = 0; i < DB; ++i)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) o[i][r] = 0.f;
+  float m_run = -1e30f, l_run = 0.f;
+
+  // K-tile row read by MFMA row i = l31 so that accumulator reg r <-> key 16*hi + r  (see header)
+  const int pi = 16 * ((l31 >> 2) & 1) + (l31 & 3) + 4 * (l31 >> 3);
+
+  stage(0, 0);
+  for (int t = 0; t < ntiles; ++t) {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    if (t + 1 < ntiles) stage((t + 1) & 1, t + 1);
+    const char* sk = smem + (t & 1) * STAGE;
+    const char* sv = sk + K_BYTES;
+
+    f32x16_t s[2];
+#pragma unroll
+    for (int kb = 0; kb < 2; ++kb) {
+#pragma unroll
+      for (int r = 0; r < 16; ++r) s[kb][r] = 0.f;
+      const int row = kb * 32 + pi;
+#pragma unroll
+      for (int ds = 0; ds < DS; ++ds) {
+        const uint4 kf = lds_read16(sk, tile_off<KCPR>(row, ds * 2 + hi));
+        s[kb] = Cvt<Tag>::mfma32(kf, qf[ds], s[kb]);
+      }
+    }
+    // ---- mask + online softmax (lane: one query, keys j0 + kb*32 + hi*16 + r)
+    const int j0 = t * KB;
+    float mx = -INFINITY;
+#pragma unroll
+    for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int j = j0 + kb * 32 + hi * 16 + r;
+        bool ok;
+        if (p.mask == 2) { const int cb = j / p.k_seq_stride; ok = (j - cb * p.k_seq_stride) < p.lk && cb == my_ctx; }
+        else ok = j < p.lk;
+        const float v = ok ? s[kb][r] * p.scale_log2e : -INFINITY;
+        s[kb][r] = v;
+        mx = fmaxf(mx, v);
+      }
+    mx = fmaxf(mx, __shfl_xor(mx, 32));
+    const float m_new = fmaxf(m_run, mx);
+    const float alpha = exp2f(m_run - m_new);
+    m_run = m_new;
+    float psum = 0.f;
+    uint4 pf[4];
+#pragma unroll
+    for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+      for (int h = 0; h < 2; ++h) {
+        float e[8];
+#pragma unroll
+        for (int r = 0; r < 8; ++r) { e[r] = exp2f(s[kb][h * 8 + r] - m_new); psum += e[r]; }
+        pf[kb * 2 + h] = pack8<Tag>(e);
+      }
+    l_run = l_run * alpha + psum;
+#pragma unroll
+    for (int i = 0; i < DB; ++i)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) o[i][r] *= alpha;
+    // ---- O^T += Vt_tile * P^T : k-slot (hi, e) of step (kb,h) is key kb*32 + 16*hi + 8*h + e
+#pragma unroll
+    for (int db = 0; db < DB; ++db) {
+      const int row = db * 32 + l31;
+#pragma unroll
+      for (int kk = 0; kk < 4; ++kk) {
+        const int chunk = (kk >> 1) * 4 + 2 * hi + (kk & 1);
+        const uint4 vf = lds_read16(sv, tile_off<8>(row, chunk));
+        o[db] = Cvt<Tag>::mfma32(vf, pf[kk], o[db]);
+      }
+    }
+  }
+  // ---- finalize: lane holds query l31, d = db*32 + 8g + 4hi + {0..3}
+  float l_tot = l_run + __shfl_xor(l_run, 32);
+  const float inv = l_tot > 0.f ? 1.0f / l_tot : 0.f;
+  if (qok) {
+    char* op = p.out + (((long)seq * p.lq + qrow) * p.ldo + head * D) * 2;
+#pragma unroll
+    for (int db = 0; db < DB; ++db)
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        const int d = db * 32 + 8 * g + 4 * hi;
+        *(uint2*)(op + d * 2) = make_uint2(pack2<Tag>(o[db][g * 4] * inv, o[db][g * 4 + 1] * inv),
+                                           pack2<Tag>(o[db][g * 4 + 2] * inv, o[db][g * 4 + 3] * inv));
+      }
+  }
+}
+
+template <typename Tag, int D>
+void launch_attn(const AttnP& p, hipStream_t st) {
+  constexpr size_t lds = 2 * (KB * D * 2 + D * KB * 2);
+  static bool attr_done = false;
+  if (!attr_done) {
+    (void)hipFuncSetAttribute((const void*)attn_kernel<Tag, D>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    attr_done = true;
+  }
+  const dim3 grid((p.lq + QB - 1) / QB, p.heads, p.nseq);
+  hipLaunchKernelGGL((attn_kernel<Tag, D>), grid, dim3(256), lds, st, p);
+}
+
+// ---------------------------------------------------------------------------------------------
+// temporal self-attention: sequence = frames (<= LPU), one LPU-lane group per (batch, pixel, head).
+// K/V rows of a block's units are staged in LDS (16-B loads), each lane = one query frame.
+template <typename Tag, int D, int LPU>
+__global__ __launch_bounds__(128) void tattn_kernel(const char* qkv, long ldqkv, char* out, long ldo, int batch,
+                                                    int frames, int hw, int heads, float scale_log2e) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  constexpr int UPB = 128 / LPU;                 // units per block
+  constexpr int ROWB = D * 2 + 16;               // padded row bytes
+  constexpr int UNITB = LPU * ROWB + 64;         // unit stride: the 4 units a wave touches sit 16 banks apart
+  const int C = heads * D;
+  const int tid = threadIdx.x;
+  const long total_units = (long)batch * hw * heads;
+  const long u0 = (long)blockIdx.x * UPB;
+  // stage K and V rows: unit u, frame f
+  const int chunks_per_row = D / 8;
+  const int nchunks = UPB * frames * chunks_per_row;
+  for (int tensor = 0; tensor < 2; ++tensor) {
+    char* dst = smem + tensor * (UPB * UNITB);
+    for (int s = tid; s < nchunks; s += 128) {
+      const int c = s % chunks_per_row, rf = s / chunks_per_row;
+      const int f = rf % frames, ul = rf / frames;
+      const long u = u0 + ul;
+      uint4 v = make_uint4(0, 0, 0, 0);
+      if (u < total_units) {
+        const int h = (int)(u % heads);
+        const long bp = u / heads;
+        const int pix = (int)(bp % hw);
+        const int b = (int)(bp / hw);
+        const long row = ((long)b * frames + f) * hw + pix;
+        v = *(const uint4*)(qkv + (row * ldqkv + (tensor + 1) * C + h * D + c * 8) * 2);
+      }
+      *(uint4*)(dst + ul * UNITB + f * ROWB + c * 16) = v;
+    }
+  }
+  __syncthreads();
+  const int ul = tid / LPU, fi = tid % LPU;
+  const long u = u0 + ul;
+  if (u >= total_units || fi >= frames) return;
+  const int h = (int)(u % heads);
+  const long bp = u / heads;
+  const int pix = (int)(bp % hw);
+  const int b = (int)(bp / hw);
+  const long qrow = ((long)b * frames + fi) * hw + pix;
+  float q[D];
+  {
+    const char* qp = qkv + (qrow * ldqkv + h * D) * 2;
+#pragma unroll
+    for (int c = 0; c < D / 8; ++c) unpack8<Tag>(*(const uint4*)(qp + c * 16), q + c * 8);
+  }
+  const char* ks = smem + ul * UNITB;
+  const char* vs = smem + UPB * UNITB + ul * UNITB;
+  float sc[LPU];
+  float mx = -INFINITY;
+#pragma unroll
+  for (int j = 0; j < LPU; ++j) {
+    float a = 0.f;
+    if (j < frames) {
+#pragma unroll
+      for (int c = 0; c < D / 8; ++c) {
+        float kf[8];
+        unpack8<Tag>(*(const uint4*)(ks + j * ROWB + c * 16), kf);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) a = fmaf(q[c * 8 + e], kf[e], a);
+      }
+      a *= scale_log2e;
+      mx = fmaxf(mx, a);
+    }
+    sc[j] = a;
+  }
+  float sum = 0.f;
+#pragma unroll
+  for (int j = 0; j < LPU; ++j) { sc[j] = j < frames ? exp2f(sc[j] - mx) : 0.f; sum += sc[j]; }
+  const float inv = 1.0f / sum;
+  float* acc = q;            // reuse registers
+#pragma unroll
+  for (int e = 0; e < D; ++e) acc[e] = 0.f;
+#pragma unroll
+  for (int j = 0; j < LPU; ++j) {
+    if (j < frames) {
+      const float pj = sc[j] * inv;
+#pragma unroll
+      for (int c = 0; c < D / 8; ++c) {
+        float vf[8];
+        unpack8<Tag>(*(const uint4*)(vs + j * ROWB + c * 16), vf);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) acc[c * 8 + e] = fmaf(pj, vf[e], acc[c * 8 + e]);
+      }
+    }
+  }
+  char* op = out + (qrow * ldo + h * D) * 2;
+#pragma unroll
+  for (int c = 0; c < D / 8; ++c) *(uint4*)(op + c * 16) = pack8<Tag>(acc + c * 8);
+}
+
+template <typename Tag, int D, int LPU>
+void launch_tattn(const void* qkv, long ldqkv, void* out, long ldo, int batch, int frames, int hw, int heads, hipStream_t st) {
+  constexpr int UPB = 128 / LPU;
+  constexpr size_t lds = 2 * UPB * (LPU * (D * 2 + 16) + 64);
+  static bool attr_done = false;
+  if (!attr_done) {
+    (void)hipFuncSetAttribute((const void*)tattn_kernel<Tag, D, LPU>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    attr_done = true;
+  }
+  const long units = (long)batch * hw * heads;
+  const float sl2 = 1.4426950408889634f / sqrtf((float)D);
+  hipLaunchKernelGGL((tattn_kernel<Tag, D, LPU>), dim3((unsigned)((units + UPB - 1) / UPB)), dim3(128), lds, st,
+                     (const char*)qkv, ldqkv, (char*)out, ldo, batch, frames, hw, heads, sl2);
+}
+
+}  // namespace
+
+extern "C" int tt_attention(const TtAttnArgs* a, tt_stream_t stream) {
+  if (!a || !a->q || !a->k || !a->vt || !a->out) TT_FAIL(TT_EINVAL, "tt_attention: null operand");
+  if (a->head_dim != 64 && a->head_dim != 128) TT_FAIL(TT_EUNSUPPORTED, "tt_attention: head_dim %d (64 or 128)", a->head_dim);
+  if (a->nseq <= 0 || a->lq <= 0 || a->heads <= 0 || a->lk <= 0) TT_FAIL(TT_EINVAL, "tt_attention: empty problem");
+  if (a->mask < 0 || a->mask > 2) TT_FAIL(TT_EINVAL, "tt_attention: mask %d", a->mask);
+  if ((a->ldq & 7) || (a->ldk & 7) || (a->ldvt & 7) || (a->ldo & 3) || (a->v_seq_stride & 7))
+    TT_FAIL(TT_EINVAL, "tt_attention: strides must keep 16-byte chunks aligned");
+  if (a->mask != 0 && (a->frames <= 0 || a->ctx_batches <= 0 || a->nseq % a->frames)) TT_FAIL(TT_EINVAL, "tt_attention: frames/ctx");
+  if (a->lk > a->k_seq_stride || a->lk > a->v_seq_stride) TT_FAIL(TT_EINVAL, "tt_attention: lk exceeds sequence stride");
+  if (a->mask == 2 && a->k_seq_stride != a->v_seq_stride) TT_FAIL(TT_EINVAL, "tt_attention: mask 2 needs equal k/v context strides");
+  if (a->dtype != TT_BF16 && a->dtype != TT_F16) TT_FAIL(TT_EINVAL, "tt_attention: bad dtype");
+  AttnP p;
+  p.q = (const char*)a->q; p.ldq = a->ldq; p.k = (const char*)a->k; p.ldk = a->ldk;
+  p.vt = (const char*)a->vt; p.ldvt = a->ldvt; p.out = (char*)a->out; p.ldo = a->ldo;
+  p.nseq = a->nseq; p.lq = a->lq; p.heads = a->heads; p.mask = a->mask; p.lk = a->lk;
+  p.k_seq_stride = a->k_seq_stride; p.v_seq_stride = a->v_seq_stride; p.frames = a->frames; p.ctx_batches = a->ctx_batches;
+  const int nctx = a->mask == 0 ? a->nseq : a->ctx_batches;
+  p.k_rows_total = nctx * a->k_seq_stride;
+  p.vt_cols_total = (long)nctx * a->v_seq_stride;
+  if (p.vt_cols_total > a->ldvt) TT_FAIL(TT_EINVAL, "tt_attention: ldvt smaller than the key columns");
+  p.scale_log2e = 1.4426950408889634f / sqrtf((float)a->head_dim);
+  hipStream_t st = (hipStream_t)stream;
+  if (a->dtype == TT_BF16) { if (a->head_dim == 64) launch_attn<bf16_tag, 64>(p, st); else launch_attn<bf16_tag, 128>(p, st); }
+  else { if (a->head_dim == 64) launch_attn<f16_tag, 64>(p, st); else launch_attn<f16_tag, 128>(p, st); }
+  TT_CHECK_LAUNCH("tt_attention");
+  return TT_OK;
+}
+
+extern "C" int tt_temporal_attention(const void* qkv, int64_t ldqkv, void* out, int64_t ldo, int32_t batch, int32_t frames,
+                                     int32_t hw, int32_t heads, int32_t head_dim, int32_t dtype, tt_stream_t stream) {
+  if (!qkv || !out) TT_FAIL(TT_EINVAL, "tt_temporal_attention: null operand");
+  if (head_dim != 64 && head_dim != 128) TT_FAIL(TT_EUNSUPPORTED, "tt_temporal_attention: head_dim %d", head_dim);
+  if (frames <= 0 || frames > 32) TT_FAIL(TT_EUNSUPPORTED, "tt_temporal_attention: frames %d (1..32)", frames);
+  if ((ldqkv & 7) || (ldo & 7)) TT_FAIL(TT_EINVAL, "tt_temporal_attention: strides");
+  if (dtype != TT_BF16 && dtype != TT_F16) TT_FAIL(TT_EINVAL, "tt_temporal_attention: bad dtype");
+  hipStream_t st = (hipStream_t)stream;
+#define TT_TA(TAG, D, L) launch_tattn<TAG, D, L>(qkv, ldqkv, out, ldo, batch, frames, hw, heads, st)
+  if (dtype == TT_BF16) {
+    if (head_dim == 64) { if (frames <= 16) TT_TA(bf16_tag, 64, 16); else TT_TA(bf16_tag, 64, 32); }
+    else { if (frames <= 16) TT_TA(bf16_tag, 128, 16); else TT_TA(bf16_tag, 128, 32); }
+  } else {
+    if (head_dim == 64) { if (frames <= 16) TT_TA(f16_tag, 64, 16); else TT_TA(f16_tag, 64, 32); }
+    else { if (frames <= 16) TT_TA(f16_tag, 128, 16); else TT_TA(f16_tag, 128, 32); }
+  }
+#undef TT_TA
+  TT_CHECK_LAUNCH("tt_temporal_attention");
+  return TT_OK;
+}

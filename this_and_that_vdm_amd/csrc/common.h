@@ -1,0 +1,91 @@
+// Shared device/host helpers for libttvdm (gfx950 only).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <stdarg.h>
+
+#include "ttvdm.h"
+
+typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8_t;
+typedef __attribute__((ext_vector_type(8))) _Float16 f16x8_t;
+typedef __attribute__((ext_vector_type(16))) float f32x16_t;
+typedef __attribute__((ext_vector_type(4))) float f32x4_t;
+
+struct bf16_tag {};
+struct f16_tag {};
+
+// 16 zero bytes (x4 for safety) that out-of-range tile lanes point their global source at.
+static __device__ __attribute__((aligned(64))) unsigned int tt_zero_page[64] = {0};   // per-TU copy: no -fgpu-rdc needed
+
+void tt_set_error(const char* fmt, ...);
+#define TT_FAIL(code, ...) do { tt_set_error(__VA_ARGS__); return (code); } while (0)
+#define TT_CHECK_LAUNCH(name) do { hipError_t e_ = hipGetLastError(); \
+    if (e_ != hipSuccess) TT_FAIL(TT_ELAUNCH, "%s: %s", name, hipGetErrorString(e_)); } while (0)
+
+// ---------------------------------------------------------------- scalar conversions
+template <typename Tag> struct Cvt;
+template <> struct Cvt<bf16_tag> {
+  static __device__ __forceinline__ float to_f32(unsigned short b) { return __uint_as_float(((unsigned)b) << 16); }
+  static __device__ __forceinline__ unsigned short from_f32(float f) {  // round-to-nearest-even
+    unsigned u = __float_as_uint(f);
+    if ((u & 0x7fffffffu) > 0x7f800000u) return (unsigned short)((u >> 16) | 0x40);
+    u += 0x7fffu + ((u >> 16) & 1u);
+    return (unsigned short)(u >> 16);
+  }
+  static __device__ __forceinline__ f32x16_t mfma32(uint4 a, uint4 b, f32x16_t c) {
+    return __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8_t, a), __builtin_bit_cast(bf16x8_t, b), c, 0, 0, 0);
+  }
+};
+template <> struct Cvt<f16_tag> {
+  static __device__ __forceinline__ float to_f32(unsigned short b) { return (float)__builtin_bit_cast(_Float16, b); }
+  static __device__ __forceinline__ unsigned short from_f32(float f) { return __builtin_bit_cast(unsigned short, (_Float16)f); }
+  static __device__ __forceinline__ f32x16_t mfma32(uint4 a, uint4 b, f32x16_t c) {
+    return __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8_t, a), __builtin_bit_cast(f16x8_t, b), c, 0, 0, 0);
+  }
+};
+
+template <typename Tag> __device__ __forceinline__ unsigned pack2(float lo, float hi) {
+  return (unsigned)Cvt<Tag>::from_f32(lo) | ((unsigned)Cvt<Tag>::from_f32(hi) << 16);
+}
+template <typename Tag> __device__ __forceinline__ void unpack8(const uint4& v, float* f) {
+  const unsigned w[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    f[2 * i] = Cvt<Tag>::to_f32((unsigned short)(w[i] & 0xffffu));
+    f[2 * i + 1] = Cvt<Tag>::to_f32((unsigned short)(w[i] >> 16));
+  }
+}
+template <typename Tag> __device__ __forceinline__ uint4 pack8(const float* f) {
+  return make_uint4(pack2<Tag>(f[0], f[1]), pack2<Tag>(f[2], f[3]), pack2<Tag>(f[4], f[5]), pack2<Tag>(f[6], f[7]));
+}
+template <typename Tag> __device__ __forceinline__ void unpack4(const uint2& v, float* f) {
+  f[0] = Cvt<Tag>::to_f32((unsigned short)(v.x & 0xffffu));
+  f[1] = Cvt<Tag>::to_f32((unsigned short)(v.x >> 16));
+  f[2] = Cvt<Tag>::to_f32((unsigned short)(v.y & 0xffffu));
+  f[3] = Cvt<Tag>::to_f32((unsigned short)(v.y >> 16));
+}
+
+__device__ __forceinline__ float silu_f(float x) { return x / (1.0f + __expf(-x)); }
+__device__ __forceinline__ float gelu_erf_f(float x) { return 0.5f * x * (1.0f + erff(x * 0.70710678118654752f)); }
+
+// ---------------------------------------------------------------- LDS tile staging (global -> LDS DMA)
+// A tile is ROWS x (CPR chunks of 16 B).  The LDS image is lane-linear (DMA requirement): slot s holds
+// the chunk (row = s / CPR, chunk' = s % CPR); the data stored there is source chunk  c = c' ^ swz(row),
+// so a reader of (row, c) looks at chunk' = c ^ swz(row).  swz spreads the 16 rows a ds_read_b128 lane
+// group touches over all 16 slots of the 256-B bank row (cdna guide section 6, guideline 4).
+template <int CPR> __device__ __forceinline__ int tile_swz(int row) {
+  if constexpr (CPR == 8) return (row >> 1) & 7;        // 128-B rows: two rows per bank row
+  else if constexpr (CPR == 16) return row & 15;        // 256-B rows
+  else return (row >> 2) & 3;                           // 64-B rows
+}
+template <int CPR> __device__ __forceinline__ int tile_off(int row, int chunk) {
+  return (row * CPR + (chunk ^ tile_swz<CPR>(row))) << 4;
+}
+__device__ __forceinline__ void glds16(const void* gsrc, char* lds_wave_base) {
+  __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)gsrc,
+                                   (__attribute__((address_space(3))) void*)lds_wave_base, 16, 0, 0);
+}
+__device__ __forceinline__ uint4 lds_read16(const char* smem, int off) { return *(const uint4*)(smem + off); }
+
+static inline int ceil_div(long a, long b) { return (int)((a + b - 1) / b); }

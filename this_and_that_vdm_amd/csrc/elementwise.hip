@@ -1,0 +1,271 @@
+// Small dense layers on a handful of rows, sinusoidal embeddings, denoise-loop glue and layout plumbing.
+#include "common.h"
+
+namespace {
+
+// y[r][n] = act_out(sum_k act_in(x[r][k]) W[n][k] + bias[n]); one wave per output column n, RT rows at a time.
+template <typename Tag, int RT>
+__global__ __launch_bounds__(256) void small_linear_kernel(const float* x, long ldx, int rows, int k, const char* w, long ldw,
+                                                           int n, const float* bias, int act_in, int act_out, int accumulate,
+                                                           float* y, long ldy) {
+  const int lane = threadIdx.x & 63;
+  const int col = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (col >= n) return;
+  const int kv = k >> 3;
+  for (int r0 = 0; r0 < rows; r0 += RT) {
+    float acc[RT];
+#pragma unroll
+    for (int r = 0; r < RT; ++r) acc[r] = 0.f;
+    for (int v = lane; v < kv; v += 64) {
+      float wf[8];
+      unpack8<Tag>(*(const uint4*)(w + ((long)col * ldw + v * 8) * 2), wf);
+#pragma unroll
+      for (int r = 0; r < RT; ++r) {
+        if (r0 + r < rows) {
+          const float* xp = x + (long)(r0 + r) * ldx + v * 8;
+          const float4 a = *(const float4*)xp, b = *(const float4*)(xp + 4);
+          float xf[8] = {a.x, a.y, a.z, a.w, b.x, b.y, b.z, b.w};
+#pragma unroll
+          for (int e = 0; e < 8; ++e) {
+            const float xv = act_in ? silu_f(xf[e]) : xf[e];
+            acc[r] = fmaf(xv, wf[e], acc[r]);
+          }
+        }
+      }
+    }
+#pragma unroll
+    for (int r = 0; r < RT; ++r) {
+      float s = acc[r];
+#pragma unroll
+      for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o);
+      if (lane == 0 && r0 + r < rows) {
+        if (bias) s += bias[col];
+        if (act_out) s = silu_f(s);
+        float* yp = y + (long)(r0 + r) * ldy + col;
+        *yp = accumulate ? *yp + s : s;
+      }
+    }
+  }
+}
+
+__global__ void timestep_embedding_kernel(const float* t, int rows, int dim, float* out, long ldo) {
+  const int half = dim >> 1;
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= rows * half) return;
+  const int r = i / half, j = i - r * half;
+  // freq_j = exp(-ln(10000) * j / half)   (downscale_freq_shift = 0); flip_sin_to_cos -> [cos | sin]
+  const float freq = expf(-9.210340371976184f * (float)j / (float)half);
+  const float arg = t[r] * freq;
+  out[(long)r * ldo + j] = cosf(arg);
+  out[(long)r * ldo + half + j] = sinf(arg);
+}
+
+template <typename Tag>
+__global__ void prep_input_kernel(const float* lat, const float* img, const float* cond, const float* sigmas, int step,
+                                  int batch, int frames, int hw, int cpad, char* x) {
+  const long total = (long)batch * frames * hw;
+  const float sg = sigmas[step];
+  const float c_in = 1.0f / sqrtf(sg * sg + 1.0f);
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+    const int p = (int)(i % hw);
+    const long bf = i / hw;
+    const int f = (int)(bf % frames);
+    const int b = (int)(bf / frames);
+    unsigned short* o = (unsigned short*)(x + i * cpad * 2);
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+      o[c] = Cvt<Tag>::from_f32(lat[((long)f * 4 + c) * hw + p] * c_in);
+      o[4 + c] = Cvt<Tag>::from_f32(img[(((long)b * frames + f) * 4 + c) * hw + p]);
+    }
+    int c0 = 8;
+    if (cond) {
+#pragma unroll
+      for (int c = 0; c < 4; ++c) o[8 + c] = Cvt<Tag>::from_f32(cond[((long)f * 4 + c) * hw + p]);
+      c0 = 12;
+    }
+    for (int c = c0; c < cpad; ++c) o[c] = 0;
+  }
+}
+
+__global__ void cfg_euler_kernel(const float* eps, int ld_eps, float* lat, const float* guidance, const float* sigmas,
+                                 int step, int batch, int frames, int hw) {
+  const long total = (long)frames * hw;
+  const float sg = sigmas[step], sn = sigmas[step + 1];
+  const float c_out = -sg / sqrtf(sg * sg + 1.0f), c_skip = 1.0f / (sg * sg + 1.0f);
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+    const int p = (int)(i % hw);
+    const int f = (int)(i / hw);
+    const float g = guidance ? guidance[f] : 1.0f;
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+      float v;
+      if (batch >= 2) {
+        const float u = eps[((long)f * hw + p) * ld_eps + c];
+        const float cd = eps[(((long)frames + f) * hw + p) * ld_eps + c];
+        v = u + g * (cd - u);
+      } else {
+        v = eps[((long)f * hw + p) * ld_eps + c];
+      }
+      float* xp = lat + ((long)f * 4 + c) * hw + p;
+      const float xv = *xp;
+      const float x0 = v * c_out + xv * c_skip;
+      *xp = xv + (xv - x0) / sg * (sn - sg);
+    }
+  }
+}
+
+// NCHW -> tokens through a 32x32 LDS transpose (coalesced both sides)
+template <typename Tag, bool SRC_F32>
+__global__ void nchw_to_tokens_kernel(const char* src, int c, int hw, char* dst, long ld_dst) {
+  __shared__ float tile[32][33];
+  const int img = blockIdx.z, c0 = blockIdx.y * 32, p0 = blockIdx.x * 32;
+  const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;     // 256 threads: ty 0..7
+  for (int i = ty; i < 32; i += 8) {
+    const int cc = c0 + i, pp = p0 + tx;
+    float v = 0.f;
+    if (cc < c && pp < hw) {
+      const long idx = ((long)img * c + cc) * hw + pp;
+      v = SRC_F32 ? ((const float*)src)[idx] : Cvt<Tag>::to_f32(((const unsigned short*)src)[idx]);
+    }
+    tile[i][tx] = v;
+  }
+  __syncthreads();
+  for (int i = ty; i < 32; i += 8) {
+    const int pp = p0 + i, cc = c0 + tx;
+    if (cc < c && pp < hw) ((unsigned short*)dst)[((long)img * hw + pp) * ld_dst + cc] = Cvt<Tag>::from_f32(tile[tx][i]);
+  }
+}
+
+template <typename Tag, bool SRC_F32, bool DST_F32>
+__global__ void tokens_to_nchw_kernel(const char* src, long ld_src, int c, int hw, char* dst) {
+  __shared__ float tile[32][33];
+  const int img = blockIdx.z, c0 = blockIdx.y * 32, p0 = blockIdx.x * 32;
+  const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
+  for (int i = ty; i < 32; i += 8) {
+    const int pp = p0 + i, cc = c0 + tx;
+    float v = 0.f;
+    if (cc < c && pp < hw) {
+      const long idx = ((long)img * hw + pp) * ld_src + cc;
+      v = SRC_F32 ? ((const float*)src)[idx] : Cvt<Tag>::to_f32(((const unsigned short*)src)[idx]);
+    }
+    tile[i][tx] = v;
+  }
+  __syncthreads();
+  for (int i = ty; i < 32; i += 8) {
+    const int cc = c0 + i, pp = p0 + tx;
+    if (cc < c && pp < hw) {
+      const long idx = ((long)img * c + cc) * hw + pp;
+      if (DST_F32) ((float*)dst)[idx] = tile[tx][i];
+      else ((unsigned short*)dst)[idx] = Cvt<Tag>::from_f32(tile[tx][i]);
+    }
+  }
+}
+
+template <typename Tag>
+__global__ void add_scaled_kernel(const char* a, const char* b, float scale, char* y, long nvec) {
+  for (long v = (long)blockIdx.x * blockDim.x + threadIdx.x; v < nvec; v += (long)gridDim.x * blockDim.x) {
+    float fa[8], fb[8];
+    unpack8<Tag>(*(const uint4*)(a + v * 16), fa);
+    unpack8<Tag>(*(const uint4*)(b + v * 16), fb);
+#pragma unroll
+    for (int e = 0; e < 8; ++e) fa[e] = fmaf(fb[e], scale, fa[e]);
+    *(uint4*)(y + v * 16) = pack8<Tag>(fa);
+  }
+}
+
+}  // namespace
+
+extern "C" int tt_small_linear(const float* x, int64_t ldx, int32_t rows, int32_t k, const void* w, int64_t ldw, int32_t n,
+                               const float* bias, int32_t act_in, int32_t act_out, int32_t accumulate, float* y, int64_t ldy,
+                               int32_t dtype, tt_stream_t stream) {
+  if (!x || !w || !y) TT_FAIL(TT_EINVAL, "tt_small_linear: null operand");
+  if (rows <= 0 || rows > 32 || n <= 0 || k <= 0 || (k & 7) || (ldx & 3) || (ldw & 7)) TT_FAIL(TT_EINVAL, "tt_small_linear: rows 1..32, k %% 8 == 0, ldx %% 4 == 0");
+  if (dtype != TT_BF16 && dtype != TT_F16) TT_FAIL(TT_EINVAL, "tt_small_linear: bad dtype");
+  hipStream_t st = (hipStream_t)stream;
+  const dim3 grid((n + 3) / 4), block(256);
+  if (dtype == TT_BF16)
+    hipLaunchKernelGGL((small_linear_kernel<bf16_tag, 4>), grid, block, 0, st, x, (long)ldx, rows, k, (const char*)w, (long)ldw, n, bias, act_in, act_out, accumulate, y, (long)ldy);
+  else
+    hipLaunchKernelGGL((small_linear_kernel<f16_tag, 4>), grid, block, 0, st, x, (long)ldx, rows, k, (const char*)w, (long)ldw, n, bias, act_in, act_out, accumulate, y, (long)ldy);
+  TT_CHECK_LAUNCH("tt_small_linear");
+  return TT_OK;
+}
+
+extern "C" int tt_timestep_embedding(const float* t, int32_t rows, int32_t dim, float* out, int64_t ldo, tt_stream_t stream) {
+  if (!t || !out || rows <= 0 || dim <= 0 || (dim & 1)) TT_FAIL(TT_EINVAL, "tt_timestep_embedding: bad arguments");
+  const int total = rows * (dim / 2);
+  hipLaunchKernelGGL(timestep_embedding_kernel, dim3((total + 255) / 256), dim3(256), 0, (hipStream_t)stream, t, rows, dim, out, (long)ldo);
+  TT_CHECK_LAUNCH("tt_timestep_embedding");
+  return TT_OK;
+}
+
+extern "C" int tt_prep_model_input(const float* latents, const float* image_latents, const float* cond, const float* sigmas,
+                                   int32_t step, int32_t batch, int32_t frames, int32_t h, int32_t w, int32_t cpad, void* x,
+                                   int32_t dtype, tt_stream_t stream) {
+  if (!latents || !image_latents || !sigmas || !x) TT_FAIL(TT_EINVAL, "tt_prep_model_input: null operand");
+  if (cpad < (cond ? 12 : 8) || (cpad & 7) || batch <= 0 || frames <= 0 || step < 0) TT_FAIL(TT_EINVAL, "tt_prep_model_input: cpad/batch/frames");
+  if (dtype != TT_BF16 && dtype != TT_F16) TT_FAIL(TT_EINVAL, "tt_prep_model_input: bad dtype");
+  const long total = (long)batch * frames * h * w;
+  long blocks = (total + 255) / 256; if (blocks > 2048) blocks = 2048;
+  hipStream_t st = (hipStream_t)stream;
+  if (dtype == TT_BF16) hipLaunchKernelGGL(prep_input_kernel<bf16_tag>, dim3((unsigned)blocks), dim3(256), 0, st, latents, image_latents, cond, sigmas, step, batch, frames, h * w, cpad, (char*)x);
+  else hipLaunchKernelGGL(prep_input_kernel<f16_tag>, dim3((unsigned)blocks), dim3(256), 0, st, latents, image_latents, cond, sigmas, step, batch, frames, h * w, cpad, (char*)x);
+  TT_CHECK_LAUNCH("tt_prep_model_input");
+  return TT_OK;
+}
+
+extern "C" int tt_cfg_euler_step(const float* eps, int32_t ld_eps, float* latents, const float* guidance, const float* sigmas,
+                                 int32_t step, int32_t batch, int32_t frames, int32_t h, int32_t w, tt_stream_t stream) {
+  if (!eps || !latents || !sigmas) TT_FAIL(TT_EINVAL, "tt_cfg_euler_step: null operand");
+  if (batch < 1 || batch > 2 || frames <= 0 || ld_eps < 4 || step < 0) TT_FAIL(TT_EINVAL, "tt_cfg_euler_step: batch must be 1 (no CFG) or 2 (uncond, cond)");
+  const long total = (long)frames * h * w;
+  long blocks = (total + 255) / 256; if (blocks > 2048) blocks = 2048;
+  hipLaunchKernelGGL(cfg_euler_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, eps, ld_eps, latents, guidance, sigmas, step, batch, frames, h * w);
+  TT_CHECK_LAUNCH("tt_cfg_euler_step");
+  return TT_OK;
+}
+
+extern "C" int tt_nchw_to_tokens(const void* src, int32_t src_f32, int32_t nimg, int32_t c, int32_t hw, void* dst, int64_t ld_dst,
+                                 int32_t dtype, tt_stream_t stream) {
+  if (!src || !dst || nimg <= 0 || c <= 0 || hw <= 0 || ld_dst < c) TT_FAIL(TT_EINVAL, "tt_nchw_to_tokens: bad arguments");
+  if (dtype != TT_BF16 && dtype != TT_F16) TT_FAIL(TT_EINVAL, "tt_nchw_to_tokens: bad dtype");
+  const dim3 grid((hw + 31) / 32, (c + 31) / 32, nimg), block(256);
+  hipStream_t st = (hipStream_t)stream;
+#define TT_N2T(TAG, F) hipLaunchKernelGGL((nchw_to_tokens_kernel<TAG, F>), grid, block, 0, st, (const char*)src, c, hw, (char*)dst, (long)ld_dst)
+  if (dtype == TT_BF16) { if (src_f32) TT_N2T(bf16_tag, true); else TT_N2T(bf16_tag, false); }
+  else { if (src_f32) TT_N2T(f16_tag, true); else TT_N2T(f16_tag, false); }
+#undef TT_N2T
+  TT_CHECK_LAUNCH("tt_nchw_to_tokens");
+  return TT_OK;
+}
+
+extern "C" int tt_tokens_to_nchw(const void* src, int32_t src_f32, int64_t ld_src, int32_t nimg, int32_t c, int32_t hw, void* dst,
+                                 int32_t dst_f32, int32_t dtype, tt_stream_t stream) {
+  if (!src || !dst || nimg <= 0 || c <= 0 || hw <= 0 || ld_src < c) TT_FAIL(TT_EINVAL, "tt_tokens_to_nchw: bad arguments");
+  if (dtype != TT_BF16 && dtype != TT_F16) TT_FAIL(TT_EINVAL, "tt_tokens_to_nchw: bad dtype");
+  const dim3 grid((hw + 31) / 32, (c + 31) / 32, nimg), block(256);
+  hipStream_t st = (hipStream_t)stream;
+#define TT_T2N(TAG, S, D) hipLaunchKernelGGL((tokens_to_nchw_kernel<TAG, S, D>), grid, block, 0, st, (const char*)src, (long)ld_src, c, hw, (char*)dst)
+  if (dtype == TT_BF16) {
+    if (src_f32) { if (dst_f32) TT_T2N(bf16_tag, true, true); else TT_T2N(bf16_tag, true, false); }
+    else { if (dst_f32) TT_T2N(bf16_tag, false, true); else TT_T2N(bf16_tag, false, false); }
+  } else {
+    if (src_f32) { if (dst_f32) TT_T2N(f16_tag, true, true); else TT_T2N(f16_tag, true, false); }
+    else { if (dst_f32) TT_T2N(f16_tag, false, true); else TT_T2N(f16_tag, false, false); }
+  }
+#undef TT_T2N
+  TT_CHECK_LAUNCH("tt_tokens_to_nchw");
+  return TT_OK;
+}
+
+extern "C" int tt_add_scaled(const void* a, const void* b, float scale, void* y, int64_t n, int32_t dtype, tt_stream_t stream) {
+  if (!a || !b || !y || n <= 0 || (n & 7)) TT_FAIL(TT_EINVAL, "tt_add_scaled: n must be a positive multiple of 8");
+  if (dtype != TT_BF16 && dtype != TT_F16) TT_FAIL(TT_EINVAL, "tt_add_scaled: bad dtype");
+  const long nvec = n >> 3;
+  long blocks = (nvec + 255) / 256; if (blocks > 4096) blocks = 4096;
+  hipStream_t st = (hipStream_t)stream;
+  if (dtype == TT_BF16) hipLaunchKernelGGL(add_scaled_kernel<bf16_tag>, dim3((unsigned)blocks), dim3(256), 0, st, (const char*)a, (const char*)b, scale, (char*)y, nvec);
+  else hipLaunchKernelGGL(add_scaled_kernel<f16_tag>, dim3((unsigned)blocks), dim3(256), 0, st, (const char*)a, (const char*)b, scale, (char*)y, nvec);
+  TT_CHECK_LAUNCH("tt_add_scaled");
+  return TT_OK;
+}

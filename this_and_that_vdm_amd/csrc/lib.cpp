@@ -1,0 +1,17 @@
+// libttvdm: version / error plumbing (host only).
+#include <stdarg.h>
+#include <stdio.h>
+#include "ttvdm.h"
+
+static thread_local char g_err[512] = "";
+
+void tt_set_error(const char* fmt, ...) {
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(g_err, sizeof g_err, fmt, ap);
+  va_end(ap);
+}
+
+extern "C" int tt_abi_version(void) { return 1; }
+extern "C" const char* tt_target_arch(void) { return "gfx950"; }
+extern "C" const char* tt_last_error(void) { return g_err; }

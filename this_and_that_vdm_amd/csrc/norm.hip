@@ -1,0 +1,230 @@
+// GroupNorm (statistics -> per-(image,channel) affine -> apply+SiLU) and LayerNorm for token-major tensors.
+// All statistics in fp32 with fp64 block/group combination (inputs reach |x| ~ 1e2 after sigma scaling).
+#include "common.h"
+
+namespace {
+
+constexpr int GN_GROUPS = 32;
+constexpr int GN_ROWS_PER_CHUNK = 64;
+
+// partial sums per (image, row-chunk, group): ws[((img*chunks + chunk)*32 + g)*2 + {0,1}] (double)
+template <typename Tag>
+__global__ void gn_partial_kernel(const char* x0, int c0, const char* x1, int c1, int hw, int chunks, double* ws) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  float* csum = (float*)smem;            // [C]
+  float* csq = csum + (c0 + c1);         // [C]
+  const int C = c0 + c1, cv = C >> 3;    // 8-channel vectors per row
+  const int img = blockIdx.y, chunk = blockIdx.x;
+  const int tid = threadIdx.x, nthr = blockDim.x;
+  for (int i = tid; i < 2 * C; i += nthr) csum[i] = 0.f;
+  __syncthreads();
+  const int rpb = nthr / cv;             // rows handled in parallel
+  const int myv = tid % cv, myr = tid / cv;
+  const int r0 = chunk * GN_ROWS_PER_CHUNK, r1 = min(hw, r0 + GN_ROWS_PER_CHUNK);
+  if (myr < rpb) {
+    float s[8], q[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) s[e] = q[e] = 0.f;
+    const int ch = myv * 8;
+    const char* base; long ld; int coff;
+    if (ch < c0) { base = x0; ld = c0; coff = ch; } else { base = x1; ld = c1; coff = ch - c0; }
+    for (int r = r0 + myr; r < r1; r += rpb) {
+      float f[8];
+      unpack8<Tag>(*(const uint4*)(base + (((long)img * hw + r) * ld + coff) * 2), f);
+#pragma unroll
+      for (int e = 0; e < 8; ++e) { s[e] += f[e]; q[e] = fmaf(f[e], f[e], q[e]); }
+    }
+#pragma unroll
+    for (int e = 0; e < 8; ++e) { atomicAdd(&csum[ch + e], s[e]); atomicAdd(&csq[ch + e], q[e]); }
+  }
+  __syncthreads();
+  if (tid < GN_GROUPS) {
+    const int cpg = C / GN_GROUPS;
+    double a = 0.0, b = 0.0;
+    for (int c = tid * cpg; c < (tid + 1) * cpg; ++c) { a += (double)csum[c]; b += (double)csq[c]; }
+    double* o = ws + (((long)img * chunks + chunk) * GN_GROUPS + tid) * 2;
+    o[0] = a; o[1] = b;
+  }
+}
+
+// one block per statistics group-set: (image-group ig) -> images [ig*fpg, (ig+1)*fpg)
+__global__ void gn_finalize_kernel(const double* ws, int chunks, int hw, int C, int fpg, const float* gamma,
+                                   const float* beta, float eps, float* scale, float* shift) {
+  __shared__ float s_mean[GN_GROUPS], s_rstd[GN_GROUPS];
+  const int ig = blockIdx.x, tid = threadIdx.x;
+  if (tid < GN_GROUPS) {
+    double a = 0.0, b = 0.0;
+    for (int f = 0; f < fpg; ++f)
+      for (int ch = 0; ch < chunks; ++ch) {
+        const double* o = ws + ((((long)ig * fpg + f) * chunks + ch) * GN_GROUPS + tid) * 2;
+        a += o[0]; b += o[1];
+      }
+    const double cnt = (double)fpg * hw * (C / GN_GROUPS);
+    const double mean = a / cnt;
+    double var = b / cnt - mean * mean;
+    if (var < 0.0) var = 0.0;
+    s_mean[tid] = (float)mean;
+    s_rstd[tid] = (float)(1.0 / sqrt(var + (double)eps));
+  }
+  __syncthreads();
+  const int cpg = C / GN_GROUPS;
+  for (int c = tid; c < C; c += blockDim.x) {
+    const int g = c / cpg;
+    const float sc = s_rstd[g] * gamma[c];
+    const float sh = beta[c] - s_mean[g] * sc;
+    for (int f = 0; f < fpg; ++f) {
+      scale[((long)ig * fpg + f) * C + c] = sc;
+      shift[((long)ig * fpg + f) * C + c] = sh;
+    }
+  }
+}
+
+template <typename Tag>
+__global__ void gn_apply_kernel(const char* x0, int c0, const char* x1, int c1, int hw, long total_vec,
+                                const float* scale, const float* shift, int silu, char* y, long ldy) {
+  const int C = c0 + c1, cv = C >> 3;
+  for (long v = (long)blockIdx.x * blockDim.x + threadIdx.x; v < total_vec; v += (long)gridDim.x * blockDim.x) {
+    const long row = v / cv;
+    const int ch = (int)(v - row * cv) * 8;
+    const int img = (int)(row / hw);
+    const char* src = ch < c0 ? x0 + (row * c0 + ch) * 2 : x1 + (row * c1 + (ch - c0)) * 2;
+    float f[8];
+    unpack8<Tag>(*(const uint4*)src, f);
+    const float4 s0 = *(const float4*)(scale + (long)img * C + ch), s1 = *(const float4*)(scale + (long)img * C + ch + 4);
+    const float4 h0 = *(const float4*)(shift + (long)img * C + ch), h1 = *(const float4*)(shift + (long)img * C + ch + 4);
+    const float sc[8] = {s0.x, s0.y, s0.z, s0.w, s1.x, s1.y, s1.z, s1.w};
+    const float sh[8] = {h0.x, h0.y, h0.z, h0.w, h1.x, h1.y, h1.z, h1.w};
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      float t = fmaf(f[e], sc[e], sh[e]);
+      f[e] = silu ? silu_f(t) : t;
+    }
+    *(uint4*)(y + (row * ldy + ch) * 2) = pack8<Tag>(f);
+  }
+}
+
+// LayerNorm: one wave per row, values kept in registers (C <= 64*8*MAXV)
+template <typename Tag, int MAXV>
+__global__ __launch_bounds__(256) void ln_kernel(const char* x, long ldx, int rows, int c, const float* gamma,
+                                                 const float* beta, float eps, const float* rowvec, int rows_per_vec,
+                                                 int nvec, char* xsum, char* y, long ldy) {
+  const int lane = threadIdx.x & 63;
+  const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (row >= rows) return;
+  const int cv = c >> 3;
+  float v[MAXV][8];
+  float s = 0.f;
+  const float* rv = rowvec ? rowvec + (long)((row / rows_per_vec) % nvec) * c : nullptr;
+#pragma unroll
+  for (int i = 0; i < MAXV; ++i) {
+    const int vi = lane + i * 64;
+    if (vi < cv) {
+      unpack8<Tag>(*(const uint4*)(x + ((long)row * ldx + vi * 8) * 2), v[i]);
+      if (rv) {
+#pragma unroll
+        for (int e = 0; e < 8; ++e) v[i][e] += rv[vi * 8 + e];
+        *(uint4*)(xsum + ((long)row * ldx + vi * 8) * 2) = pack8<Tag>(v[i]);
+      }
+#pragma unroll
+      for (int e = 0; e < 8; ++e) s += v[i][e];
+    }
+  }
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o);
+  const float mean = s / c;
+  float q = 0.f;
+#pragma unroll
+  for (int i = 0; i < MAXV; ++i) {
+    const int vi = lane + i * 64;
+    if (vi < cv) {
+#pragma unroll
+      for (int e = 0; e < 8; ++e) { const float d = v[i][e] - mean; q = fmaf(d, d, q); }
+    }
+  }
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) q += __shfl_xor(q, o);
+  const float rstd = rsqrtf(q / c + eps);
+#pragma unroll
+  for (int i = 0; i < MAXV; ++i) {
+    const int vi = lane + i * 64;
+    if (vi < cv) {
+      float o8[8];
+#pragma unroll
+      for (int e = 0; e < 8; ++e) o8[e] = (v[i][e] - mean) * rstd * gamma[vi * 8 + e] + beta[vi * 8 + e];
+      *(uint4*)(y + ((long)row * ldy + vi * 8) * 2) = pack8<Tag>(o8);
+    }
+  }
+}
+
+}  // namespace
+
+extern "C" size_t tt_groupnorm_ws_bytes(int32_t nimg, int32_t hw, int32_t c) {
+  (void)c;
+  const long chunks = (hw + GN_ROWS_PER_CHUNK - 1) / GN_ROWS_PER_CHUNK;
+  return (size_t)nimg * chunks * GN_GROUPS * 2 * sizeof(double);
+}
+
+extern "C" int tt_groupnorm_stats(const void* x0, int32_t c0, const void* x1, int32_t c1, int32_t nimg, int32_t hw,
+                                  int32_t fpg, const float* gamma, const float* beta, float eps, float* scale, float* shift,
+                                  void* ws, size_t ws_bytes, int32_t dtype, tt_stream_t stream) {
+  const int C = c0 + c1;
+  if (!x0 || !gamma || !beta || !scale || !shift || !ws) TT_FAIL(TT_EINVAL, "tt_groupnorm_stats: null operand");
+  if (c1 && !x1) TT_FAIL(TT_EINVAL, "tt_groupnorm_stats: c1 without x1");
+  if (nimg <= 0 || hw <= 0 || C <= 0 || (C % GN_GROUPS) || (c0 & 7) || (c1 & 7)) TT_FAIL(TT_EINVAL, "tt_groupnorm_stats: C=%d+%d must be a multiple of 32, sources of 8", c0, c1);
+  if (fpg <= 0 || nimg % fpg) TT_FAIL(TT_EINVAL, "tt_groupnorm_stats: frames_per_group %d does not divide %d images", fpg, nimg);
+  if (ws_bytes < tt_groupnorm_ws_bytes(nimg, hw, C)) TT_FAIL(TT_EINVAL, "tt_groupnorm_stats: workspace too small");
+  if (dtype != TT_BF16 && dtype != TT_F16) TT_FAIL(TT_EINVAL, "tt_groupnorm_stats: bad dtype");
+  const int cv = C >> 3;
+  if (cv > 1024) TT_FAIL(TT_EUNSUPPORTED, "tt_groupnorm_stats: C=%d too wide", C);
+  const int chunks = (hw + GN_ROWS_PER_CHUNK - 1) / GN_ROWS_PER_CHUNK;
+  int rpb = 256 / cv; if (rpb < 1) rpb = 1;
+  int threads = cv * rpb; if (threads < GN_GROUPS) threads = GN_GROUPS;
+  threads = (threads + 63) / 64 * 64;
+  hipStream_t st = (hipStream_t)stream;
+  const size_t lds = (size_t)2 * C * sizeof(float);
+  if (dtype == TT_BF16)
+    hipLaunchKernelGGL(gn_partial_kernel<bf16_tag>, dim3(chunks, nimg), dim3(threads), lds, st, (const char*)x0, c0, (const char*)x1, c1, hw, chunks, (double*)ws);
+  else
+    hipLaunchKernelGGL(gn_partial_kernel<f16_tag>, dim3(chunks, nimg), dim3(threads), lds, st, (const char*)x0, c0, (const char*)x1, c1, hw, chunks, (double*)ws);
+  hipLaunchKernelGGL(gn_finalize_kernel, dim3(nimg / fpg), dim3(256), 0, st, (const double*)ws, chunks, hw, C, fpg, gamma, beta, eps, scale, shift);
+  TT_CHECK_LAUNCH("tt_groupnorm_stats");
+  return TT_OK;
+}
+
+extern "C" int tt_groupnorm_apply(const void* x0, int32_t c0, const void* x1, int32_t c1, int32_t nimg, int32_t hw,
+                                  const float* scale, const float* shift, int32_t silu, void* y, int64_t ldy, int32_t dtype,
+                                  tt_stream_t stream) {
+  const int C = c0 + c1;
+  if (!x0 || !scale || !shift || !y) TT_FAIL(TT_EINVAL, "tt_groupnorm_apply: null operand");
+  if (c1 && !x1) TT_FAIL(TT_EINVAL, "tt_groupnorm_apply: c1 without x1");
+  if ((c0 & 7) || (c1 & 7) || (ldy & 7) || ldy < C) TT_FAIL(TT_EINVAL, "tt_groupnorm_apply: channel counts/stride must be multiples of 8");
+  if (dtype != TT_BF16 && dtype != TT_F16) TT_FAIL(TT_EINVAL, "tt_groupnorm_apply: bad dtype");
+  const long total = (long)nimg * hw * (C >> 3);
+  long blocks = (total + 255) / 256; if (blocks > 4096) blocks = 4096;
+  hipStream_t st = (hipStream_t)stream;
+  if (dtype == TT_BF16)
+    hipLaunchKernelGGL(gn_apply_kernel<bf16_tag>, dim3((unsigned)blocks), dim3(256), 0, st, (const char*)x0, c0, (const char*)x1, c1, hw, total, scale, shift, silu, (char*)y, (long)ldy);
+  else
+    hipLaunchKernelGGL(gn_apply_kernel<f16_tag>, dim3((unsigned)blocks), dim3(256), 0, st, (const char*)x0, c0, (const char*)x1, c1, hw, total, scale, shift, silu, (char*)y, (long)ldy);
+  TT_CHECK_LAUNCH("tt_groupnorm_apply");
+  return TT_OK;
+}
+
+extern "C" int tt_layernorm(const void* x, int64_t ldx, int32_t rows, int32_t c, const float* gamma, const float* beta,
+                            float eps, const float* rowvec, int32_t rows_per_vec, int32_t nvec, void* xsum_out, void* y,
+                            int64_t ldy, int32_t dtype, tt_stream_t stream) {
+  if (!x || !gamma || !beta || !y) TT_FAIL(TT_EINVAL, "tt_layernorm: null operand");
+  if (rows <= 0 || c <= 0 || (c & 7) || (ldx & 7) || (ldy & 7)) TT_FAIL(TT_EINVAL, "tt_layernorm: c and strides must be multiples of 8");
+  if (rowvec && (!xsum_out || rows_per_vec <= 0 || nvec <= 0)) TT_FAIL(TT_EINVAL, "tt_layernorm: rowvec needs xsum_out, rows_per_vec, nvec");
+  if (c > 64 * 8 * 4) TT_FAIL(TT_EUNSUPPORTED, "tt_layernorm: c=%d > 2048", c);
+  if (dtype != TT_BF16 && dtype != TT_F16) TT_FAIL(TT_EINVAL, "tt_layernorm: bad dtype");
+  hipStream_t st = (hipStream_t)stream;
+  const dim3 grid((rows + 3) / 4), block(256);
+#define TT_LN(TAG, MV) hipLaunchKernelGGL((ln_kernel<TAG, MV>), grid, block, 0, st, (const char*)x, (long)ldx, rows, c, gamma, beta, eps, rowvec, rows_per_vec, nvec, (char*)xsum_out, (char*)y, (long)ldy)
+  const int mv = (c / 8 + 63) / 64;
+  if (dtype == TT_BF16) { if (mv <= 1) TT_LN(bf16_tag, 1); else if (mv <= 2) TT_LN(bf16_tag, 2); else TT_LN(bf16_tag, 4); }
+  else { if (mv <= 1) TT_LN(f16_tag, 1); else if (mv <= 2) TT_LN(f16_tag, 2); else TT_LN(f16_tag, 4); }
+#undef TT_LN
+  TT_CHECK_LAUNCH("tt_layernorm");
+  return TT_OK;
+}

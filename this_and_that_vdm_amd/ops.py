@@ -1,0 +1,214 @@
+"""Thin torch-tensor front end over the C ABI (include/ttvdm.h).  torch supplies device memory and the
+current HIP stream only; every op below is a libttvdm kernel launch and raises if the library is
+missing or the tensors are not on a HIP device."""
+from __future__ import annotations
+
+import ctypes as C
+from typing import Optional, Tuple
+
+import torch
+
+from . import _lib
+from ._lib import TT_BF16, TT_F16, TtAttnArgs, TtGemmArgs, check
+
+
+def _code(dt: torch.dtype) -> int:
+    if dt == torch.bfloat16:
+        return TT_BF16
+    if dt == torch.float16:
+        return TT_F16
+    raise RuntimeError(f"libttvdm activations/weights must be bfloat16 or float16, got {dt}")
+
+
+def _stream():
+    return C.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def _p(t: Optional[torch.Tensor]):
+    if t is None:
+        return None
+    if not t.is_cuda:
+        raise RuntimeError("libttvdm ops need tensors on the HIP device (no CPU fallback)")
+    return t.data_ptr()
+
+
+def _rows2d(t: torch.Tensor) -> Tuple[int, int]:
+    """(row stride, cols) of a 2-D row view whose last dim is contiguous."""
+    assert t.dim() == 2 and t.stride(1) == 1, (t.shape, t.stride())
+    return t.stride(0), t.shape[1]
+
+
+def gemm(a0: torch.Tensor, w: torch.Tensor, *, a1: Optional[torch.Tensor] = None, mode: int = 0, conv=None, tconv=None,
+         bias=None, acc_scale: float = 1.0, rowvec=None, rowvec_rows: int = 0, geglu: bool = False, residual=None,
+         blend=None, alpha: float = 0.0, out: Optional[torch.Tensor] = None, out_f32: bool = False, m: Optional[int] = None,
+         out_col_pad: Optional[Tuple[int, int]] = None) -> torch.Tensor:
+    """out[m, n] = epilogue(gather(a0|a1) @ w.T); see TtGemmArgs in include/ttvdm.h.
+    conv = (nimg, hin, win, hout, wout, stride, upsample); tconv = (frames, hw)."""
+    lib = _lib.load()
+    g = TtGemmArgs()
+    lda0, k0 = _rows2d(a0)
+    g.a0, g.k0, g.lda0 = _p(a0), k0, lda0
+    if a1 is not None:
+        lda1, k1 = _rows2d(a1)
+        g.a1, g.k1, g.lda1 = _p(a1), k1, lda1
+    ldw, _ = _rows2d(w)
+    n = w.shape[0]
+    g.w, g.ldw, g.n = _p(w), ldw, n
+    g.mode = mode
+    if mode == 1:
+        g.nimg, g.hin, g.win, g.hout, g.wout, g.stride, g.upsample = conv
+        mm = conv[0] * conv[3] * conv[4]
+    elif mode == 2:
+        g.frames, g.hw = tconv
+        mm = a0.shape[0]
+    else:
+        mm = a0.shape[0]
+    g.m = mm if m is None else m
+    g.bias, g.acc_scale = _p(bias), acc_scale
+    if rowvec is not None:
+        g.rowvec, g.rowvec_rows, g.ld_rowvec = _p(rowvec), rowvec_rows, rowvec.stride(0)
+    g.geglu = int(geglu)
+    if residual is not None:
+        g.residual, g.ld_res = _p(residual), residual.stride(0)
+    if blend is not None:
+        g.blend, g.ld_blend, g.alpha = _p(blend), blend.stride(0), alpha
+    n_out = n // 2 if geglu else n
+    if out is None:
+        out = torch.empty((g.m, n_out), dtype=torch.float32 if out_f32 else a0.dtype, device=a0.device)
+    g.out, g.ldo, g.out_f32 = _p(out), out.stride(0), int(out_f32)
+    if out_col_pad is not None:
+        g.out_col_hw, g.out_col_hwp = out_col_pad
+    g.dtype = _code(a0.dtype)
+    check(lib.tt_gemm(C.byref(g), _stream()), "tt_gemm")
+    return out
+
+
+def attention(q, k, vt, out, *, nseq, lq, heads, head_dim, mask, lk, k_seq_stride, v_seq_stride, frames=1, ctx_batches=1):
+    lib = _lib.load()
+    a = TtAttnArgs()
+    a.q, a.ldq = _p(q), q.stride(0)
+    a.k, a.ldk = _p(k), k.stride(0)
+    a.vt, a.ldvt = _p(vt), vt.stride(0)
+    a.out, a.ldo = _p(out), out.stride(0)
+    a.nseq, a.lq, a.heads, a.head_dim = nseq, lq, heads, head_dim
+    a.mask, a.lk, a.k_seq_stride, a.v_seq_stride = mask, lk, k_seq_stride, v_seq_stride
+    a.frames, a.ctx_batches, a.dtype = frames, ctx_batches, _code(q.dtype)
+    check(lib.tt_attention(C.byref(a), _stream()), "tt_attention")
+    return out
+
+
+def temporal_attention(qkv, out, *, batch, frames, hw, heads, head_dim):
+    lib = _lib.load()
+    check(lib.tt_temporal_attention(_p(qkv), qkv.stride(0), _p(out), out.stride(0), batch, frames, hw, heads, head_dim,
+                                    _code(qkv.dtype), _stream()), "tt_temporal_attention")
+    return out
+
+
+def groupnorm_stats(x0, x1, nimg, hw, frames_per_group, gamma, beta, eps):
+    """-> (scale, shift) fp32 [nimg, C] with y = x*scale + shift."""
+    lib = _lib.load()
+    c0 = x0.shape[-1]
+    c1 = 0 if x1 is None else x1.shape[-1]
+    c = c0 + c1
+    ws_bytes = lib.tt_groupnorm_ws_bytes(nimg, hw, c)
+    ws = torch.empty(ws_bytes // 8, dtype=torch.float64, device=x0.device)
+    scale = torch.empty((nimg, c), dtype=torch.float32, device=x0.device)
+    shift = torch.empty_like(scale)
+    check(lib.tt_groupnorm_stats(_p(x0), c0, _p(x1), c1, nimg, hw, frames_per_group, _p(gamma), _p(beta), eps,
+                                 _p(scale), _p(shift), _p(ws), ws_bytes, _code(x0.dtype), _stream()), "tt_groupnorm_stats")
+    return scale, shift
+
+
+def groupnorm_apply(x0, x1, nimg, hw, scale, shift, silu: bool, out=None):
+    lib = _lib.load()
+    c0 = x0.shape[-1]
+    c1 = 0 if x1 is None else x1.shape[-1]
+    if out is None:
+        out = torch.empty((nimg * hw, c0 + c1), dtype=x0.dtype, device=x0.device)
+    check(lib.tt_groupnorm_apply(_p(x0), c0, _p(x1), c1, nimg, hw, _p(scale), _p(shift), int(silu), _p(out), out.stride(0),
+                                 _code(x0.dtype), _stream()), "tt_groupnorm_apply")
+    return out
+
+
+def layernorm(x, gamma, beta, eps=1e-5, rowvec=None, rows_per_vec=0, nvec=0):
+    """-> y, or (x + rowvec, y) when a row vector is fused in."""
+    lib = _lib.load()
+    rows, c = x.shape
+    y = torch.empty((rows, c), dtype=x.dtype, device=x.device)
+    xs = torch.empty((rows, c), dtype=x.dtype, device=x.device) if rowvec is not None else None
+    if xs is not None:
+        assert x.stride(0) == c
+    check(lib.tt_layernorm(_p(x), x.stride(0), rows, c, _p(gamma), _p(beta), eps, _p(rowvec), rows_per_vec, nvec, _p(xs),
+                           _p(y), y.stride(0), _code(x.dtype), _stream()), "tt_layernorm")
+    return (xs, y) if xs is not None else y
+
+
+def small_linear(x, w, bias=None, act_in=False, act_out=False, out=None, accumulate=False):
+    lib = _lib.load()
+    rows, k = x.shape
+    n = w.shape[0]
+    if out is None:
+        out = torch.empty((rows, n), dtype=torch.float32, device=x.device)
+    assert x.dtype == torch.float32 and out.dtype == torch.float32
+    check(lib.tt_small_linear(_p(x), x.stride(0), rows, k, _p(w), w.stride(0), n, _p(bias), int(act_in), int(act_out),
+                              int(accumulate), _p(out), out.stride(0), _code(w.dtype), _stream()), "tt_small_linear")
+    return out
+
+
+def timestep_embedding(t, dim):
+    lib = _lib.load()
+    assert t.dtype == torch.float32 and t.dim() == 1
+    out = torch.empty((t.shape[0], dim), dtype=torch.float32, device=t.device)
+    check(lib.tt_timestep_embedding(_p(t), t.shape[0], dim, _p(out), out.stride(0), _stream()), "tt_timestep_embedding")
+    return out
+
+
+def prep_model_input(latents, image_latents, cond, sigmas, step, batch, frames, h, w, cpad, dtype):
+    lib = _lib.load()
+    x = torch.empty((batch * frames * h * w, cpad), dtype=dtype, device=latents.device)
+    check(lib.tt_prep_model_input(_p(latents), _p(image_latents), _p(cond), _p(sigmas), step, batch, frames, h, w, cpad,
+                                  _p(x), _code(dtype), _stream()), "tt_prep_model_input")
+    return x
+
+
+def cfg_euler_step(eps, latents, guidance, sigmas, step, batch, frames, h, w):
+    lib = _lib.load()
+    check(lib.tt_cfg_euler_step(_p(eps), eps.stride(0), _p(latents), _p(guidance), _p(sigmas), step, batch, frames, h, w,
+                                _stream()), "tt_cfg_euler_step")
+    return latents
+
+
+def nchw_to_tokens(src, dtype, ld=None):
+    """[N,C,H,W] contiguous (fp32 or `dtype`) -> [N*H*W, ld>=C] token-major `dtype` (extra columns zero)."""
+    lib = _lib.load()
+    n, c, h, w = src.shape
+    src = src.contiguous()
+    ld = c if ld is None else ld
+    dst = (torch.zeros if ld != c else torch.empty)((n * h * w, ld), dtype=dtype, device=src.device)
+    if src.dtype not in (torch.float32, dtype):
+        src = src.float()
+    check(lib.tt_nchw_to_tokens(_p(src), int(src.dtype == torch.float32), n, c, h * w, _p(dst), ld, _code(dtype), _stream()),
+          "tt_nchw_to_tokens")
+    return dst
+
+
+def tokens_to_nchw(src, n, c, h, w, out_dtype):
+    lib = _lib.load()
+    src_f32 = src.dtype == torch.float32
+    tok_dtype = out_dtype if src_f32 and out_dtype != torch.float32 else (src.dtype if not src_f32 else torch.bfloat16)
+    dst_f32 = out_dtype == torch.float32
+    if not dst_f32 and not src_f32:
+        assert out_dtype == src.dtype
+    dst = torch.empty((n, c, h, w), dtype=out_dtype, device=src.device)
+    check(lib.tt_tokens_to_nchw(_p(src), int(src_f32), src.stride(0), n, c, h * w, _p(dst), int(dst_f32), _code(tok_dtype),
+                                _stream()), "tt_tokens_to_nchw")
+    return dst
+
+
+def add_scaled(a, b, scale=1.0, out=None):
+    lib = _lib.load()
+    assert a.is_contiguous() and b.is_contiguous() and a.shape == b.shape
+    if out is None:
+        out = torch.empty_like(a)
+    check(lib.tt_add_scaled(_p(a), _p(b), scale, _p(out), a.numel(), _code(a.dtype), _stream()), "tt_add_scaled")
+    return out
