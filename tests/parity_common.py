@@ -1,0 +1,80 @@
+"""Shared by tests/test_model_gpu.py and __graft_entry__.smoke(): run the HIP product models and the CPU
+oracle on the same deterministic weights/inputs and report error statistics."""
+import os
+
+import numpy as np
+import torch
+
+GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+
+TINY = {
+    "tiny_vgl": dict(block_out_channels=(64, 128, 256, 256), num_attention_heads=(1, 2, 4, 4), cross_attention_dim=64, num_frames=4),
+    "tiny_vl_d128": dict(block_out_channels=(64, 128, 256, 256), num_attention_heads=(1, 2, 2, 4), cross_attention_dim=64, num_frames=3),
+}
+
+
+def load_golden(name):
+    z = np.load(os.path.join(GOLDEN, f"{name}.npz"))
+    return {k: torch.from_numpy(z[k]) if z[k].ndim else z[k] for k in z.files}
+
+
+def err_stats(got: torch.Tensor, ref: torch.Tensor) -> dict:
+    got, ref = got.detach().float().cpu().flatten(), ref.detach().float().cpu().flatten()
+    d = got - ref
+    return dict(max_abs=float(d.abs().max()), ref_absmax=float(ref.abs().max()),
+                rel_l2=float(d.norm() / ref.norm().clamp_min(1e-30)),
+                cos=float(torch.nn.functional.cosine_similarity(got, ref, dim=0)))
+
+
+def build_pair(name, dtype, device, with_controlnet):
+    """(product unet, product controlnet | None, oracle unet, oracle controlnet | None) with identical,
+    dtype-rounded weights."""
+    from oracle import models as om
+    from this_and_that_vdm_amd.svd.temporal_controlnet import ControlNetModel
+    from this_and_that_vdm_amd.svd.unet_spatio_temporal_condition import UNetSpatioTemporalConditionModel
+    from this_and_that_vdm_amd.utils.synthetic import fill_parameters_
+    kw = dict(TINY[name])
+    o_unet = om.UNetSpatioTemporalConditionModel(**kw).eval()
+    fill_parameters_(o_unet, "unet.", round_to=dtype)
+    p_unet = UNetSpatioTemporalConditionModel(**kw).eval()
+    p_unet.load_state_dict(o_unet.state_dict())
+    p_unet = p_unet.to(device=device, dtype=dtype)
+    o_cn = p_cn = None
+    if with_controlnet:
+        kw.pop("num_frames")
+        o_cn = om.ControlNetModel(**kw).eval()
+        fill_parameters_(o_cn, "controlnet.", round_to=dtype)
+        p_cn = ControlNetModel(**kw).eval()
+        p_cn.load_state_dict(o_cn.state_dict())
+        p_cn = p_cn.to(device=device, dtype=dtype)
+    return p_unet, p_cn, o_unet, o_cn
+
+
+@torch.no_grad()
+def run_tiny_vgl_parity(dtype, device="cuda:0", name="tiny_vgl"):
+    g = load_golden(name)
+    with_cn = "cn_mid" in g
+    p_unet, p_cn, o_unet, o_cn = build_pair(name, dtype, device, with_cn)
+    t = float(g["timestep"])
+    x, ehs, ati = g["sample"], g["encoder_hidden_states"], g["added_time_ids"]
+    dev = lambda v: v.to(device)
+    stats = {}
+    ref_vl = o_unet(x, t, ehs, ati)
+    got_vl = p_unet(dev(x), t, dev(ehs), dev(ati), return_dict=False)[0]
+    assert got_vl.shape == ref_vl.shape and got_vl.dtype == torch.float32
+    stats["unet_vl_vs_oracle"] = err_stats(got_vl, ref_vl)
+    stats["unet_vl_vs_reference_vectors"] = err_stats(got_vl, g["unet_vl"])
+    if with_cn:
+        cond = g["controlnet_cond"]
+        rd, rm = o_cn(x, t, ehs, ati, controlnet_cond=cond, conditioning_scale=0.75)
+        gd, gm = p_cn(dev(x), t, dev(ehs), dev(ati), controlnet_cond=dev(cond), conditioning_scale=0.75, return_dict=False)
+        assert isinstance(gd, list) and len(gd) == 12
+        for i, (a, b) in enumerate(zip(gd, rd)):
+            assert a.shape == b.shape, (i, a.shape, b.shape)
+        stats["cn_down_worst_vs_oracle"] = max((err_stats(a, b) for a, b in zip(gd, rd)), key=lambda s: s["rel_l2"])
+        stats["cn_mid_vs_oracle"] = err_stats(gm, rm)
+        ref = o_unet(x, t, ehs, ati, down_block_additional_residuals=rd, mid_block_additional_residual=rm)
+        got = p_unet(dev(x), t, dev(ehs), dev(ati), down_block_additional_residuals=gd, mid_block_additional_residual=gm).sample
+        stats["unet_vgl_vs_oracle"] = err_stats(got, ref)
+        stats["unet_vgl_vs_reference_vectors"] = err_stats(got, g["unet_vgl"])
+    return stats

@@ -178,18 +178,21 @@ def cfg_euler_step(eps, latents, guidance, sigmas, step, batch, frames, h, w):
     return latents
 
 
-def nchw_to_tokens(src, dtype, ld=None):
-    """[N,C,H,W] contiguous (fp32 or `dtype`) -> [N*H*W, ld>=C] token-major `dtype` (extra columns zero)."""
+def nchw_to_tokens(src, dtype, ld=None, out=None):
+    """[N,C,H,W] contiguous (fp32 or `dtype`) -> token-major `dtype` [N*H*W, ld>=C] (extra columns zero), or into
+    ``out`` (a [N*H*W, C] column window of a wider token buffer)."""
     lib = _lib.load()
     n, c, h, w = src.shape
     src = src.contiguous()
-    ld = c if ld is None else ld
-    dst = (torch.zeros if ld != c else torch.empty)((n * h * w, ld), dtype=dtype, device=src.device)
     if src.dtype not in (torch.float32, dtype):
         src = src.float()
-    check(lib.tt_nchw_to_tokens(_p(src), int(src.dtype == torch.float32), n, c, h * w, _p(dst), ld, _code(dtype), _stream()),
-          "tt_nchw_to_tokens")
-    return dst
+    if out is None:
+        ld = c if ld is None else ld
+        out = (torch.zeros if ld != c else torch.empty)((n * h * w, ld), dtype=dtype, device=src.device)
+    assert out.dtype == dtype and out.stride(1) == 1
+    check(lib.tt_nchw_to_tokens(_p(src), int(src.dtype == torch.float32), n, c, h * w, _p(out), out.stride(0), _code(dtype),
+                                _stream()), "tt_nchw_to_tokens")
+    return out
 
 
 def tokens_to_nchw(src, n, c, h, w, out_dtype):

@@ -1,0 +1,110 @@
+"""What UNetSpatioTemporalConditionModel and ControlNetModel share: weight packing, the time/FiLM embedding
+path, the per-request context K/V projection and the encoder walk."""
+from __future__ import annotations
+
+from typing import List, Optional, Tuple
+
+import torch
+import torch.nn as nn
+
+from .. import ops
+from .layers import Geom, PackRegistry, StepContext, _f32
+from .modeling_utils import ModelMixin
+from ..packing import pack_conv3x3
+
+
+def as_tokens(t: torch.Tensor, dtype: torch.dtype) -> torch.Tensor:
+    """logical [N,C,h,w] -> token view [N*h*w, C]; zero-copy when the tensor is already channels-last `dtype`."""
+    n, c, h, w = t.shape
+    if t.dtype == dtype and t.permute(0, 2, 3, 1).is_contiguous():
+        return t.permute(0, 2, 3, 1).reshape(n * h * w, c)
+    return ops.nchw_to_tokens(t, dtype)
+
+
+def as_nchw_view(tok: torch.Tensor, g: Geom) -> torch.Tensor:
+    """token buffer -> logical [N,C,h,w] tensor (channels-last strides, no copy)."""
+    return tok.view(g.n, g.h, g.w, tok.shape[1]).permute(0, 3, 1, 2)
+
+
+class DenoiserBase(ModelMixin):
+    compute_dtype: Optional[torch.dtype] = None      # None: parameter dtype if 16-bit, else bf16
+
+    # ---- packing
+    def _pack_key(self):
+        p0 = next(self.parameters())
+        return (p0.device, self._run_dtype(), sum(p._version for p in self.parameters()))
+
+    def _run_dtype(self) -> torch.dtype:
+        if self.compute_dtype is not None:
+            return self.compute_dtype
+        dt = self.dtype
+        return dt if dt in (torch.float16, torch.bfloat16) else torch.bfloat16
+
+    def prepare(self, force: bool = False):
+        """Pack weights for the kernels (lazy; repeated when parameters move or change)."""
+        key = self._pack_key()
+        if not force and getattr(self, "_packed_key", None) == key:
+            return self
+        if next(self.parameters()).device.type != "cuda":
+            raise RuntimeError(f"{type(self).__name__}: the denoise path runs on the MI355X only; move the model to the "
+                               "HIP device first (there is no CPU fallback)")
+        dtype = key[1]
+        reg = PackRegistry()
+        self._pack_modules(reg, dtype)
+        self._film_w = torch.cat(reg.film_w, 0).to(dtype).contiguous()
+        self._film_b = torch.cat(reg.film_b, 0).float().contiguous()
+        self._k_w = torch.cat(reg.k_w, 0).to(dtype).contiguous()
+        self._v_w = torch.cat(reg.v_w, 0).to(dtype).contiguous()
+        self._packed_key = self._pack_key()
+        return self
+
+    def _pack_modules(self, reg: PackRegistry, dtype):
+        raise NotImplementedError
+
+    # ---- embeddings (unet_spatio_temporal_condition.py:399-432 == temporal_controlnet.py:527-560)
+    def _embed(self, timestep, added_time_ids, batch: int, device) -> torch.Tensor:
+        if not torch.is_tensor(timestep):
+            t = torch.full((batch,), float(timestep), dtype=torch.float32, device=device)
+        else:
+            t = timestep.to(device=device, dtype=torch.float32).reshape(-1).expand(batch).contiguous()
+        emb = self.time_embedding(self.time_proj(t))
+        ids = added_time_ids.to(device=device, dtype=torch.float32).reshape(-1).contiguous()
+        te = self.add_time_proj(ids).reshape(batch, -1)
+        ae = self.add_embedding
+        hid = ops.small_linear(te, ae.w1, ae.b1, act_out=True)
+        return ops.small_linear(hid, ae.w2, ae.b2, out=emb, accumulate=True)     # emb + aug_emb, fp32 [B, 1280]
+
+    def project_context(self, encoder_hidden_states: torch.Tensor):
+        """K / V^T of every cross-attention layer from the request's context: two GEMMs, step-invariant.
+        Returns an opaque tuple accepted by forward(..., _context=...)."""
+        self.prepare()
+        dtype = self._run_dtype()
+        b, s, d = encoder_hidden_states.shape
+        sp = (s + 7) // 8 * 8
+        pad = torch.zeros((b, sp, d), dtype=dtype, device=encoder_hidden_states.device)
+        pad[:, :s] = encoder_hidden_states.to(dtype)
+        pad = pad.view(b * sp, d)
+        k_all = ops.gemm(pad, self._k_w)                              # [B*Sp, sumC]
+        vt_all = ops.gemm(self._v_w, pad)                             # [sumC, B*Sp]
+        return (k_all, vt_all, s, sp)
+
+    def _step_context(self, emb: torch.Tensor, context) -> StepContext:
+        film = ops.small_linear(emb, self._film_w, self._film_b, act_in=True)     # every ResBlock's FiLM row at once
+        k_all, vt_all, s, sp = context
+        return StepContext(film, k_all, vt_all, s, sp)
+
+    # ---- encoder walk shared by both models
+    def _encode(self, x, g: Geom, ctx: StepContext):
+        skips: List[Tuple[torch.Tensor, Geom]] = [(x, g)]
+        for blk in self.down_blocks:
+            x, g, outs = blk(x, g, ctx)
+            skips.extend(outs)
+        return x, g, skips
+
+    def _apply(self, fn, *a, **k):
+        self._packed_key = None
+        return super()._apply(fn, *a, **k)
+
+    def load_state_dict(self, *a, **k):
+        self._packed_key = None
+        return super().load_state_dict(*a, **k)

@@ -1,0 +1,77 @@
+"""TransformerSpatioTemporalModel on libttvdm kernels (reference: svd/diffusion_arch/transformer_temporal.py:201-381).
+
+GroupNorm -> proj_in -> [spatial block ; + frame-position embedding ; temporal block ; alpha-blend] -> proj_out -> +x.
+Differences from the reference's execution (results identical up to storage rounding):
+  * tokens stay [(B F), hw, C] throughout: no NCHW<->token permutes (:325,374) and no (B F)<->(B hw) copies;
+  * the temporal cross-attention context is NOT materialised per pixel (:316-319); the (hw,B) pairing it
+    implies is reproduced by index arithmetic inside tt_attention (mask 2);
+  * frame-position embeddings (:328-339) are step-invariant and cached per frame count;
+  * AlphaBlender (:366-370) is the epilogue of the temporal block's last GEMM.
+"""
+from __future__ import annotations
+
+from dataclasses import dataclass
+from typing import Dict, Optional
+
+import torch
+import torch.nn as nn
+
+from ... import ops
+from ..layers import (AlphaBlender, BasicTransformerBlock, Geom, StepContext, TemporalBasicTransformerBlock,
+                      TimestepEmbedding, Timesteps, _f32, _gn, _Packable)
+from ..modeling_utils import BaseOutput
+
+
+@dataclass
+class TransformerTemporalModelOutput(BaseOutput):
+    sample: torch.Tensor = None
+
+
+class TransformerSpatioTemporalModel(_Packable):
+    def __init__(self, num_attention_heads: int = 16, attention_head_dim: int = 88, in_channels: int = 320,
+                 out_channels: Optional[int] = None, num_layers: int = 1, cross_attention_dim: Optional[int] = None):
+        super().__init__()
+        self.num_attention_heads, self.attention_head_dim = num_attention_heads, attention_head_dim
+        inner_dim = num_attention_heads * attention_head_dim
+        if inner_dim != in_channels:
+            raise NotImplementedError("SVD transformers keep inner_dim == in_channels")
+        self.inner_dim, self.in_channels = inner_dim, in_channels
+        self.norm = nn.GroupNorm(32, in_channels, eps=1e-6)
+        self.proj_in = nn.Linear(in_channels, inner_dim)
+        self.transformer_blocks = nn.ModuleList(
+            [BasicTransformerBlock(inner_dim, num_attention_heads, attention_head_dim, cross_attention_dim=cross_attention_dim)
+             for _ in range(num_layers)])
+        self.temporal_transformer_blocks = nn.ModuleList(
+            [TemporalBasicTransformerBlock(inner_dim, inner_dim, num_attention_heads, attention_head_dim,
+                                           cross_attention_dim=cross_attention_dim) for _ in range(num_layers)])
+        self.time_pos_embed = TimestepEmbedding(in_channels, in_channels * 4, out_dim=in_channels)
+        self.time_proj = Timesteps(in_channels, True, 0)
+        self.time_mixer = AlphaBlender(alpha=0.5, merge_strategy="learned_with_images")
+        self.out_channels = in_channels if out_channels is None else out_channels
+        self.proj_out = nn.Linear(inner_dim, in_channels)
+        self._pos_cache: Dict[int, torch.Tensor] = {}
+
+    def pack(self, reg, dtype):
+        self.gn = (_f32(self.norm.weight), _f32(self.norm.bias))
+        self.w_in, self.b_in = self.proj_in.weight.detach().to(dtype).contiguous(), _f32(self.proj_in.bias)
+        self.w_out, self.b_out = self.proj_out.weight.detach().to(dtype).contiguous(), _f32(self.proj_out.bias)
+        for blk in list(self.transformer_blocks) + list(self.temporal_transformer_blocks):
+            blk.pack(reg, dtype)
+        self.time_pos_embed.pack(reg, dtype)
+        self.alpha = self.time_mixer.alpha_value()
+        self._pos_cache = {}
+
+    def _pos_emb(self, frames: int, device) -> torch.Tensor:
+        if frames not in self._pos_cache:
+            idx = torch.arange(frames, device=device, dtype=torch.float32)
+            self._pos_cache[frames] = self.time_pos_embed(self.time_proj(idx))          # fp32 [F, C]
+        return self._pos_cache[frames]
+
+    def forward(self, x, g: Geom, ctx: StepContext):
+        xn = _gn(x, None, g, 1, self.gn[0], self.gn[1], 1e-6, False)
+        hs = ops.gemm(xn, self.w_in, bias=self.b_in)
+        pos = self._pos_emb(g.frames, x.device)
+        for blk, tblk in zip(self.transformer_blocks, self.temporal_transformer_blocks):
+            hs = blk(hs, g, ctx)
+            hs = tblk(hs, pos, g, ctx, self.alpha)
+        return ops.gemm(hs, self.w_out, bias=self.b_out, residual=x)
