@@ -1,0 +1,230 @@
+#!/usr/bin/env python3
+"""denoise-steps/sec of the SVD denoise hot path (GestureNet ControlNet + spatio-temporal UNet + CFG + Euler),
+BASELINE.json's metric, on N MI355X GPUs of one node.
+
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--mode vgl|vl] [--res lo|hi] [--dtype bf16|fp16]
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
+
+One "step" = one iteration of the reference loop body
+(svd/pipeline_stable_video_diffusion_controlnet.py:624-720) for one request: CFG batch 2 x 14 frames,
+78 context tokens, heads (5,10,20,20), random-init weights of the real architecture (1.52 B + 0.68 B
+parameters), synthetic inputs.  Each rank serves its own independent request (weak scaling,
+no collective inside the step); rank 0's weights reach the other ranks by ONE RCCL broadcast at start-up.
+Inputs are resident in HBM when the timed region starts.  Rank 0 prints one JSON line.
+"""
+import argparse
+import json
+import math
+import os
+import sys
+import time
+
+import torch
+
+REPO = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, REPO)
+
+# algorithmic TFLOP per denoise step (2*MAC for conv/Linear/QK^T/PV, context K/V counted once per batch element):
+# BASELINE.md section 2 / SURVEY.md 8(d)
+STEP_TFLOP = {("vgl", "lo"): 20.10, ("vl", "lo"): 14.77, ("vgl", "hi"): 91.32, ("vl", "hi"): 66.89}
+LATENT = {"lo": (32, 56), "hi": (64, 112)}
+PEAK_TFLOPS = 2500.0          # dense bf16/fp16 MFMA peak, MI355X_MICROARCH.md (spec ~2.5 PF; 2495 measured)
+FRAMES, CTX_TOKENS, CTX_DIM, STEPS_PER_REQUEST = 14, 78, 1024, 25
+
+
+def build_models(mode, dtype, device, rank, world):
+    from this_and_that_vdm_amd.svd.temporal_controlnet import ControlNetModel
+    from this_and_that_vdm_amd.svd.unet_spatio_temporal_condition import UNetSpatioTemporalConditionModel
+    from this_and_that_vdm_amd.utils.synthetic import fill_parameters_
+    models = []
+    with torch.device(device):
+        unet = UNetSpatioTemporalConditionModel(num_attention_heads=(5, 10, 20, 20), num_frames=FRAMES).to(dtype).eval()
+        models.append(("unet.", unet))
+        cn = None
+        if mode == "vgl":
+            cn = ControlNetModel().to(dtype).eval()
+            models.append(("controlnet.", cn))
+    from this_and_that_vdm_amd.dist import broadcast_model_, flat_param_buffer
+    bcast_s = None
+    for salt, m in models:
+        flat = flat_param_buffer(m)
+        if rank == 0:
+            fill_parameters_(m, salt)            # zero-convs get non-zero values too
+        if world > 1:
+            bcast_s = (bcast_s or 0.0) + broadcast_model_(m, src=0, flat=flat)     # RCCL over xGMI, once
+        m.prepare(force=True)
+    return unet, cn, bcast_s
+
+
+def make_loop(unet, cn, res, device, seed):
+    from this_and_that_vdm_amd.svd.denoise import DenoiseLoop
+    from this_and_that_vdm_amd.svd.scheduling_euler_discrete import EulerDiscreteScheduler
+    from this_and_that_vdm_amd.utils.synthetic import synthetic_inputs
+    h, w = LATENT[res]
+    inp = synthetic_inputs(2, FRAMES, h, w, CTX_TOKENS, CTX_DIM, seed=seed)
+    sched = EulerDiscreteScheduler()
+    sched.set_timesteps(STEPS_PER_REQUEST)
+    loop = DenoiseLoop(unet, cn, use_graph=True)
+    args = dict(latents=inp["latents"], image_latents=inp["image_latents"], encoder_hidden_states=inp["encoder_hidden_states"],
+                added_time_ids=inp["added_time_ids"], guidance_scale=inp["guidance_scale"], sigmas=sched.sigmas,
+                timesteps=sched.timesteps, controlnet_cond=inp["gesture_latents"] if cn is not None else None)
+    loop.begin(**args)
+    return loop, args
+
+
+def advance(loop, args, n):
+    for _ in range(n):
+        if loop.step_index == loop.num_steps:       # next request (same shapes -> same captured graph)
+            loop.begin(**args)
+        loop.step()
+
+
+def kernel_profile(loop, args):
+    """One eager (un-captured) step with HIP events around every tt_gemm / tt_attention launch on the launch
+    stream -> per kernel-instance (launch count, algorithmic flops, time)."""
+    from this_and_that_vdm_amd import ops
+    loop.begin(**args)
+    loop.use_graph = False
+    loop.step()                                     # eager warm-up
+    torch.cuda.synchronize()
+    ops.PROFILE = []
+    loop.step()
+    torch.cuda.synchronize()
+    rec, ops.PROFILE = ops.PROFILE, None
+    loop.use_graph = True
+    agg = {}
+    for name, flops, e0, e1 in rec:
+        a = agg.setdefault(name, [0, 0.0, 0.0])
+        a[0] += 1
+        a[1] += flops
+        a[2] += e0.elapsed_time(e1) * 1e-3
+    return agg
+
+
+def cpu_baseline(mode, res):
+    """The oracle (CPU restatement of the reference's eager op sequence, fp32) timed on this box's host cores on a
+    bounded sample: one ControlNet + one UNet forward for ONE CFG half (B=1, 14 frames); a step is two halves."""
+    from oracle import models as om
+    cores = os.cpu_count() or 1
+    torch.set_num_threads(cores)
+    h, w = LATENT[res]
+    pat = torch.randn(1 << 20, generator=torch.Generator().manual_seed(0)) * 0.02
+
+    torch.set_flush_denormal(True)
+
+    def cheap_fill(m):          # timing does not depend on the values; avoid a minutes-long RNG init of 2.2 B params
+        for name, p in m.named_parameters():
+            n = p.numel()
+            p.data.view(-1).copy_(pat.repeat((n + pat.numel() - 1) // pat.numel())[:n])
+            if p.dim() == 1 and name.endswith("weight"):
+                p.data.fill_(1.0)
+
+    with torch.no_grad():
+        unet = om.UNetSpatioTemporalConditionModel(num_attention_heads=(5, 10, 20, 20), num_frames=FRAMES).eval()
+        cheap_fill(unet)
+        x = torch.randn(1, FRAMES, 8, h, w)
+        ehs = torch.randn(1, CTX_TOKENS, CTX_DIM)
+        ati = torch.tensor([[6.0, 200.0, 0.1]])
+        t0 = time.perf_counter()
+        down = mid = None
+        if mode == "vgl":
+            cn = om.ControlNetModel().eval()
+            cheap_fill(cn)
+            t0 = time.perf_counter()
+            down, mid = cn(x, 1.0, ehs, ati, controlnet_cond=torch.randn(FRAMES, 4, h, w))
+        unet(x, 1.0, ehs, ati, down_block_additional_residuals=down, mid_block_additional_residual=mid)
+        half = time.perf_counter() - t0
+    return {"value": 1.0 / (2.0 * half), "unit": "denoise-steps/s", "cores": cores, "kind": "port",
+            "sample": f"oracle fp32 eager, 1 {'ControlNet+' if mode == 'vgl' else ''}UNet forward of one CFG half "
+                      f"(B=1, {FRAMES}x4x{h}x{w}) = {half:.1f} s, untimed warm-up none; step = 2 halves (extrapolated)"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=25)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--mode", choices=["vgl", "vl"], default="vgl")
+    ap.add_argument("--res", choices=["lo", "hi"], default="lo")
+    ap.add_argument("--dtype", choices=["bf16", "fp16"], default="bf16")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-kernel-profile", action="store_true")
+    a = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != a.gpus:
+        raise SystemExit(f"--gpus {a.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run --nproc-per-node {a.gpus}")
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs MI355X GPUs (the denoise path has no CPU fallback)")
+    torch.cuda.set_device(local)
+    device = torch.device("cuda", local)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        torch.distributed.init_process_group("nccl", device_id=device)
+    dtype = torch.bfloat16 if a.dtype == "bf16" else torch.float16
+
+    unet, cn, bcast_s = build_models(a.mode, dtype, device, rank, world)
+    loop, args = make_loop(unet, cn, a.res, device, seed=rank)
+
+    def fence():
+        torch.cuda.synchronize()
+        if world > 1:
+            torch.distributed.barrier()
+            torch.cuda.synchronize()
+
+    advance(loop, args, a.warmup)
+    fence()
+    t0 = time.perf_counter()
+    advance(loop, args, a.steps)
+    fence()
+    dt = time.perf_counter() - t0
+    from this_and_that_vdm_amd.dist import max_over_ranks
+    dt = max_over_ranks(dt, device)
+    finite = bool(torch.isfinite(loop.result()).all().item())
+
+    roofline, extras = None, {}
+    if rank == 0 and not a.no_kernel_profile:
+        agg = kernel_profile(loop, args)
+        tot_flops = sum(v[1] for v in agg.values())
+        name, (cnt, fl, sec) = max(agg.items(), key=lambda kv: kv[1][2])
+        roofline = {"bound": "mfma", "kernel": name, "launches_per_step": cnt,
+                    "achieved": fl / sec / 1e12, "peak": PEAK_TFLOPS, "unit": "TFLOP/s",
+                    "frac": fl / sec / 1e12 / PEAK_TFLOPS, "traffic": None,
+                    "algorithmic_gflop_per_launch": fl / cnt / 1e9, "avg_launch_us": sec / cnt * 1e6}
+        extras["mfma_kernels"] = {k: {"launches": v[0], "tflop": v[1] / 1e12, "ms": v[2] * 1e3,
+                                      "tflops": v[1] / v[2] / 1e12} for k, v in sorted(agg.items(), key=lambda kv: -kv[1][2])}
+        extras["executed_tflop_per_step"] = tot_flops / 1e12
+    cpu = None
+    if rank == 0 and world == 1 and not a.no_cpu_baseline:
+        cpu = cpu_baseline(a.mode, a.res)
+
+    if rank == 0:
+        h, w = LATENT[a.res]
+        ms = dt / a.steps * 1e3
+        step_tflop = STEP_TFLOP[(a.mode, a.res)]
+        out = {
+            "metric": "denoise-steps/sec (14-frame 256x448 VGL, 25 steps)" if (a.mode, a.res) == ("vgl", "lo")
+                      else f"denoise-steps/sec (14-frame {h * 8}x{w * 8} {a.mode.upper()}, 25 steps)",
+            "value": world * a.steps / dt, "unit": "denoise-steps/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
+            "ms_per_step": ms, "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": a.dtype,
+            "data": "synthetic (random-init weights of the real architecture, seeded inputs)",
+            "config": {"workload": f"{a.mode.upper()} denoise step: {'GestureNet ControlNet + ' if a.mode == 'vgl' else ''}"
+                                   f"spatio-temporal UNet + per-frame CFG + Euler, latent {FRAMES}x4x{h}x{w}, CFG batch 2, "
+                                   f"{CTX_TOKENS} context tokens, heads (5,10,20,20)",
+                       "mode": a.mode, "latent": [FRAMES, 4, h, w], "requests_per_gpu": 1,
+                       "parallelism": f"{world} independent request(s), one per GPU; RCCL weight broadcast at start-up only",
+                       "hipgraph": True, "finite_output": finite,
+                       "step_tflop_algorithmic": step_tflop,
+                       "step_mfma_frac_of_peak": step_tflop / (ms * 1e-3) / PEAK_TFLOPS,
+                       "weight_broadcast_s": bcast_s, **extras},
+            "roofline": roofline, "cpu_baseline": cpu,
+        }
+        print(json.dumps(out))
+    if world > 1:
+        torch.distributed.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

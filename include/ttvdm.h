@@ -76,6 +76,9 @@ typedef struct TtGemmArgs {
   int32_t dtype;
 } TtGemmArgs;
 int tt_gemm(const TtGemmArgs* args, tt_stream_t stream);
+/* which BM x BN workgroup tile tt_gemm will use for (m, n): lets a profiler name the kernel instance
+ * (gemm_kernel<dtype,BM,BN,2,2,mode>) a launch maps to.  Host-only, no launch. */
+int tt_gemm_plan(const TtGemmArgs* args, int32_t* bm, int32_t* bn);
 
 /* ------------------------------------------------------------------------------------------------
  * tt_attention: softmax(Q K^T / sqrt(d)) V with online softmax on MFMA tiles; replaces

@@ -47,6 +47,7 @@ SIGNATURES = {
     "tt_target_arch": (C.c_char_p, []),
     "tt_last_error": (C.c_char_p, []),
     "tt_gemm": (C.c_int, [C.POINTER(TtGemmArgs), _vp]),
+    "tt_gemm_plan": (C.c_int, [C.POINTER(TtGemmArgs), C.POINTER(C.c_int32), C.POINTER(C.c_int32)]),
     "tt_attention": (C.c_int, [C.POINTER(TtAttnArgs), _vp]),
     "tt_temporal_attention": (C.c_int, [_vp, _i64, _vp, _i64, _i32, _i32, _i32, _i32, _i32, _i32, _vp]),
     "tt_groupnorm_ws_bytes": (_sz, [_i32, _i32, _i32]),

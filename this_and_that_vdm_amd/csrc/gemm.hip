@@ -283,17 +283,33 @@ int launch_cfg(GemmP& p, hipStream_t st) {
   return 0;
 }
 
+// Tile choice: the largest tile that still gives the 256 CUs about two waves of workgroups.
+void choose_tile(int m, int n, int* bm, int* bn) {
+  const long b128 = (long)ceil_div(m, 128) * ceil_div(n, 128);
+  const long b12864 = (long)ceil_div(m, 128) * ceil_div(n, 64);
+  if (b128 >= 384) { *bm = 128; *bn = 128; }
+  else if (b12864 >= 384) { *bm = 128; *bn = 64; }
+  else { *bm = 64; *bn = 64; }
+}
+
 template <typename Tag>
 int launch(GemmP& p, hipStream_t st) {
-  // Tile choice: the largest tile that still gives the 256 CUs about two waves of workgroups.
-  const long b128 = (long)ceil_div(p.m, 128) * ceil_div(p.n, 128);
-  const long b12864 = (long)ceil_div(p.m, 128) * ceil_div(p.n, 64);
-  if (b128 >= 384) return launch_cfg<Tag, 128, 128, 2, 2>(p, st);
-  if (b12864 >= 384) return launch_cfg<Tag, 128, 64, 2, 2>(p, st);
+  int bm, bn;
+  choose_tile(p.m, p.n, &bm, &bn);
+  if (bm == 128 && bn == 128) return launch_cfg<Tag, 128, 128, 2, 2>(p, st);
+  if (bm == 128) return launch_cfg<Tag, 128, 64, 2, 2>(p, st);
   return launch_cfg<Tag, 64, 64, 2, 2>(p, st);
 }
 
 }  // namespace
+
+extern "C" int tt_gemm_plan(const TtGemmArgs* a, int32_t* bm, int32_t* bn) {
+  if (!a || !bm || !bn || a->m <= 0 || a->n <= 0) TT_FAIL(TT_EINVAL, "tt_gemm_plan: bad arguments");
+  int x, y;
+  choose_tile(a->m, a->n, &x, &y);
+  *bm = x; *bn = y;
+  return TT_OK;
+}
 
 extern "C" int tt_gemm(const TtGemmArgs* a, tt_stream_t stream) {
   if (!a || !a->a0 || !a->w || !a->out) TT_FAIL(TT_EINVAL, "tt_gemm: null operand");

@@ -12,6 +12,26 @@ from . import _lib
 from ._lib import TT_BF16, TT_F16, TtAttnArgs, TtGemmArgs, check
 
 
+# Optional launch profiler (bench.py): when set to a list, gemm()/attention() append
+# (kernel instance name, algorithmic flops, start event, end event) around their launch on the current stream.
+PROFILE = None
+
+
+def _prof_begin():
+    if PROFILE is None:
+        return None
+    e = torch.cuda.Event(enable_timing=True)
+    e.record()
+    return e
+
+
+def _prof_end(start, name, flops):
+    if start is not None:
+        e = torch.cuda.Event(enable_timing=True)
+        e.record()
+        PROFILE.append((name, flops, start, e))
+
+
 def _code(dt: torch.dtype) -> int:
     if dt == torch.bfloat16:
         return TT_BF16
@@ -79,7 +99,14 @@ def gemm(a0: torch.Tensor, w: torch.Tensor, *, a1: Optional[torch.Tensor] = None
     if out_col_pad is not None:
         g.out_col_hw, g.out_col_hwp = out_col_pad
     g.dtype = _code(a0.dtype)
+    ev = _prof_begin()
     check(lib.tt_gemm(C.byref(g), _stream()), "tt_gemm")
+    if ev is not None:
+        bm, bn = C.c_int32(), C.c_int32()
+        lib.tt_gemm_plan(C.byref(g), C.byref(bm), C.byref(bn))
+        taps = 9 if mode == 1 else (3 if mode == 2 else 1)
+        tag = "bf16_tag" if g.dtype == TT_BF16 else "f16_tag"
+        _prof_end(ev, f"gemm_kernel<{tag},{bm.value},{bn.value},2,2,{mode}>", 2.0 * g.m * n * taps * (g.k0 + g.k1))
     return out
 
 
@@ -93,7 +120,12 @@ def attention(q, k, vt, out, *, nseq, lq, heads, head_dim, mask, lk, k_seq_strid
     a.nseq, a.lq, a.heads, a.head_dim = nseq, lq, heads, head_dim
     a.mask, a.lk, a.k_seq_stride, a.v_seq_stride = mask, lk, k_seq_stride, v_seq_stride
     a.frames, a.ctx_batches, a.dtype = frames, ctx_batches, _code(q.dtype)
+    ev = _prof_begin()
     check(lib.tt_attention(C.byref(a), _stream()), "tt_attention")
+    if ev is not None:
+        tag = "bf16_tag" if a.dtype == TT_BF16 else "f16_tag"
+        keys = lk * (ctx_batches if mask == 2 else 1)
+        _prof_end(ev, f"attn_kernel<{tag},{head_dim}>", 4.0 * nseq * heads * lq * (lk if mask != 2 else lk) * head_dim)
     return out
 
 

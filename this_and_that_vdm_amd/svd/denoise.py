@@ -1,0 +1,123 @@
+"""The fused denoise loop: the body of StableVideoDiffusion(ControlNet)Pipeline.__call__'s step loop
+(svd/pipeline_stable_video_diffusion_controlnet.py:624-720, VL twin svd/pipeline_stable_video_diffusion.py:528-562)
+as ONE hipGraph replayed per step.
+
+Per step, on device:   prep (CFG duplicate, x/sqrt(sigma^2+1), channel concat, NCHW->tokens)  ->  time/FiLM rows
+  ->  UNet encoder+mid  ->  GestureNet encoder+mid, zero-convs with the UNet skips added in the epilogue
+  ->  UNet decoder  ->  per-frame CFG + v-prediction Euler update of the fp32 latents (in place).
+Hoisted out of the loop (step-invariant; the reference recomputes them every step):
+context K/V of all 46 cross-attention layers, frame-position embeddings, and the gesture-map latents (the
+pipeline VAE-encodes them once instead of 25 times, reference :652).
+Step-dependent scalars (sigma_i, sigma_{i+1}, t_i) live in a 3-float device buffer that is refreshed by one
+tiny copy before each replay, so a single captured graph serves all steps.  No host sync inside the loop."""
+from __future__ import annotations
+
+from typing import Optional
+
+import torch
+
+from .. import ops
+from .layers import Geom
+
+
+class DenoiseLoop:
+    def __init__(self, unet, controlnet=None, use_graph: bool = True):
+        self.unet, self.controlnet, self.use_graph = unet, controlnet, use_graph
+        self._graph = None
+        self._key = None
+
+    # ---- request set-up (everything step-invariant)
+    def begin(self, latents: torch.Tensor, image_latents: torch.Tensor, encoder_hidden_states: torch.Tensor,
+              added_time_ids: torch.Tensor, guidance_scale: Optional[torch.Tensor], sigmas: torch.Tensor,
+              timesteps: torch.Tensor, controlnet_cond: Optional[torch.Tensor] = None, conditioning_scale: float = 1.0):
+        """latents [1,F,4,h,w] (already scaled by init_noise_sigma); image_latents [B,F,4,h,w]; encoder_hidden_states
+        [B,S,D]; added_time_ids [B,3]; guidance_scale [1,F,1,1,1] or None (no CFG: B == 1); sigmas [steps+1],
+        timesteps [steps]; controlnet_cond [F,4,h,w] gesture latents (same for both CFG halves, reference :660)."""
+        dev = self.unet.device
+        self.unet.prepare()
+        b = image_latents.shape[0]
+        _, f, _, h, w = latents.shape
+        if b not in (1, 2):
+            raise NotImplementedError("CFG batch of 1 or 2 (use_instructpix2pix triples it; not built)")
+        self.geom = Geom(b, f, h, w)
+        self.dtype = self.unet._run_dtype()
+        f32 = lambda t: t.to(device=dev, dtype=torch.float32).contiguous()
+        self.latents = f32(latents).clone().view(f, 4, h, w)
+        self.image_latents = f32(image_latents)
+        self.added_time_ids = f32(added_time_ids)
+        self.guidance = f32(guidance_scale).reshape(-1) if guidance_scale is not None else None
+        self.table = torch.stack([f32(sigmas)[:-1], f32(sigmas)[1:], f32(timesteps)], 1).contiguous()   # [steps, 3]
+        self.cur = torch.zeros(3, dtype=torch.float32, device=dev)                                    # sigma, sigma_next, t
+        self.num_steps = self.table.shape[0]
+        self.ctx_unet = self.unet.project_context(encoder_hidden_states.to(dev))
+        self.cond = None
+        if self.controlnet is not None:
+            if controlnet_cond is None:
+                raise ValueError("controlnet_cond (VAE-encoded gesture latents) is required with a ControlNet")
+            self.controlnet.prepare()
+            if self.controlnet._run_dtype() != self.dtype:
+                raise RuntimeError("UNet and ControlNet must run in the same 16-bit dtype inside the fused loop")
+            self.cond = f32(controlnet_cond).view(f, 4, h, w)
+            self.ctx_cn = self.controlnet.project_context(encoder_hidden_states.to(dev))
+            self.cn_scales = self.controlnet._scales(float(conditioning_scale), False, len(self.controlnet.controlnet_down_blocks))
+        key = (b, f, h, w, self.dtype, self.controlnet is not None, encoder_hidden_states.shape[1])
+        if key != self._key:
+            self._graph, self._key = None, key
+        self.step_index = 0
+        return self
+
+    # ---- one step's launches (captured once)
+    def _launch_step(self):
+        g = self.geom
+        cpad = self.controlnet._cin_pad if self.controlnet is not None else self.unet._cin_pad
+        x_tok = ops.prep_model_input(self.latents, self.image_latents, self.cond, self.cur, 0, g.batch, g.frames, g.h, g.w,
+                                     cpad, self.dtype)
+        t = self.cur[2:3]
+        emb_u = self.unet._embed(t, self.added_time_ids, g.batch, x_tok.device)
+        ctx_u = self.unet._step_context(emb_u, self.ctx_unet)
+        x_unet = x_tok if cpad == self.unet._cin_pad else x_tok[:, :self.unet._cin_pad]
+        x, gm, skips = self.unet.encode_tokens(x_unet, g, ctx_u)
+        if self.controlnet is not None:
+            emb_c = self.controlnet._embed(t, self.added_time_ids, g.batch, x_tok.device)
+            down, (x, _) = self.controlnet.forward_tokens(x_tok, g, emb_c, self.ctx_cn, self.cn_scales,
+                                                          add_to=([s for s, _ in skips], x))
+            skips = down
+        eps = self.unet.decode_tokens(x, gm, skips, ctx_u)
+        ops.cfg_euler_step(eps, self.latents, self.guidance, self.cur, 0, g.batch, g.frames, g.h, g.w)
+
+    def step(self):
+        """Advance the latents by one Euler step (asynchronous; call torch.cuda.synchronize() to wait)."""
+        if self.step_index >= self.num_steps:
+            raise RuntimeError("denoise loop already finished; call begin() for a new request")
+        self.cur.copy_(self.table[self.step_index])
+        if not self.use_graph:
+            self._launch_step()
+        else:
+            if self._graph is None:
+                self._capture()
+            self._graph.replay()
+        self.step_index += 1
+
+    def _capture(self):
+        # warm-up on a side stream (allocator + lazily built caches), restoring the latents afterwards
+        keep = self.latents.clone()
+        s = torch.cuda.Stream()
+        s.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(s):
+            self._launch_step()
+        torch.cuda.current_stream().wait_stream(s)
+        graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(graph):
+            self._launch_step()
+        self.latents.copy_(keep)
+        self._graph = graph
+
+    def run(self, steps: Optional[int] = None) -> torch.Tensor:
+        n = self.num_steps - self.step_index if steps is None else steps
+        for _ in range(n):
+            self.step()
+        return self.result()
+
+    def result(self) -> torch.Tensor:
+        g = self.geom
+        return self.latents.view(1, g.frames, 4, g.h, g.w)

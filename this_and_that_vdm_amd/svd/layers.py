@@ -47,13 +47,18 @@ class StepContext:
 
     def __init__(self, film: torch.Tensor, k_all: torch.Tensor, vt_all: torch.Tensor, s_ctx: int, s_pad: int):
         self.film, self.k_all, self.vt_all, self.s_ctx, self.s_pad = film, k_all, vt_all, s_ctx, s_pad
-        self._vt_cache: Dict[tuple, torch.Tensor] = {}
+
+    _VT_CACHE: Dict[tuple, torch.Tensor] = {}
 
     def vt_buffer(self, c: int, cols: int, like: torch.Tensor) -> torch.Tensor:
-        key = (c, cols)
-        if key not in self._vt_cache:
-            self._vt_cache[key] = torch.zeros((c, cols), dtype=like.dtype, device=like.device)
-        return self._vt_cache[key]
+        """Scratch for the transposed V projection of self-attention.  Persistent per shape: padding columns
+        (sequence length not a multiple of 8) are zeroed once and never written, and launches on one stream
+        are ordered, so layers can share it."""
+        key = (like.device, like.dtype, c, cols)
+        buf = StepContext._VT_CACHE.get(key)
+        if buf is None:
+            buf = StepContext._VT_CACHE[key] = torch.zeros((c, cols), dtype=like.dtype, device=like.device)
+        return buf
 
 
 class PackRegistry:

@@ -111,22 +111,33 @@ class UNetSpatioTemporalConditionModel(DenoiserBase, ConfigMixin):
         self._w_out, self._b_out = pack_conv3x3(self.conv_out.weight.detach().to(dtype)), _f32(self.conv_out.bias)
 
     # ---- forward
-    def forward_tokens(self, x_tok, g: Geom, emb, context, down_res_tok=None, mid_res_tok=None):
-        """Token-level core: x_tok [M, cin_pad] -> eps fp32 [M, out_channels] (used by forward() and the fused loop)."""
-        ctx = self._step_context(emb, context)
+    def encode_tokens(self, x_tok, g: Geom, ctx):
+        """conv_in + 4 down blocks + mid block -> (x_mid, geom_mid, skips[12]) ; no ControlNet terms yet."""
         x = ops.gemm(x_tok, self._w_in, mode=1, conv=(g.n, g.h, g.w, g.h, g.w, 1, 0), bias=self._b_in)
         x, gm, skips = self._encode(x, g, ctx)
-        if down_res_tok is not None:                                   # :481-491 -- after the whole encoder (quirk Q4)
-            if len(down_res_tok) != len(skips):
-                raise ValueError(f"expected {len(skips)} down-block residuals, got {len(down_res_tok)}")
-            skips = [(ops.add_scaled(s, r), sg) for (s, sg), r in zip(skips, down_res_tok)]
-        x = self.mid_block(x, gm, ctx)
-        if mid_res_tok is not None:
-            x = ops.add_scaled(x, mid_res_tok)
+        return self.mid_block(x, gm, ctx), gm, skips
+
+    def decode_tokens(self, x, gm: Geom, skips, ctx):
+        """4 up blocks + GN/SiLU/conv_out -> eps fp32 [M, out_channels]."""
+        skips = list(skips)
         for blk in self.up_blocks:
             x, gm = blk(x, skips, gm, ctx)
         a = _gn(x, None, gm, 1, self._gn_out[0], self._gn_out[1], 1e-5, True)
         return ops.gemm(a, self._w_out, mode=1, conv=(gm.n, gm.h, gm.w, gm.h, gm.w, 1, 0), bias=self._b_out, out_f32=True)
+
+    def forward_tokens(self, x_tok, g: Geom, emb, context, down_res_tok=None, mid_res_tok=None):
+        """Token-level core: x_tok [M, cin_pad] -> eps fp32 [M, out_channels].  The reference adds the ControlNet
+        residuals to all 12 skips after the encoder and to the mid output (:481-502, quirk Q4); the mid block
+        itself never sees them, so encode+mid can run before the residuals exist."""
+        ctx = self._step_context(emb, context)
+        x, gm, skips = self.encode_tokens(x_tok, g, ctx)
+        if down_res_tok is not None:
+            if len(down_res_tok) != len(skips):
+                raise ValueError(f"expected {len(skips)} down-block residuals, got {len(down_res_tok)}")
+            skips = [(ops.add_scaled(s, r), sg) for (s, sg), r in zip(skips, down_res_tok)]
+        if mid_res_tok is not None:
+            x = ops.add_scaled(x, mid_res_tok)
+        return self.decode_tokens(x, gm, skips, ctx)
 
     def forward(
         self,
