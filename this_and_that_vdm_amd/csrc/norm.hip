@@ -11,14 +11,13 @@ constexpr int GN_ROWS_PER_CHUNK = 64;
 template <typename Tag>
 __global__ void gn_partial_kernel(const char* x0, int c0, const char* x1, int c1, int hw, int chunks, double* ws) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
-  float* csum = (float*)smem;            // [C]
-  float* csq = csum + (c0 + c1);         // [C]
+  // per-(row-lane, channel) partial sums, reduced in a fixed order: results are bit-reproducible
   const int C = c0 + c1, cv = C >> 3;    // 8-channel vectors per row
   const int img = blockIdx.y, chunk = blockIdx.x;
   const int tid = threadIdx.x, nthr = blockDim.x;
-  for (int i = tid; i < 2 * C; i += nthr) csum[i] = 0.f;
-  __syncthreads();
   const int rpb = nthr / cv;             // rows handled in parallel
+  float* psum = (float*)smem;            // [rpb][C]
+  float* psq = psum + rpb * C;           // [rpb][C]
   const int myv = tid % cv, myr = tid / cv;
   const int r0 = chunk * GN_ROWS_PER_CHUNK, r1 = min(hw, r0 + GN_ROWS_PER_CHUNK);
   if (myr < rpb) {
@@ -35,30 +34,44 @@ __global__ void gn_partial_kernel(const char* x0, int c0, const char* x1, int c1
       for (int e = 0; e < 8; ++e) { s[e] += f[e]; q[e] = fmaf(f[e], f[e], q[e]); }
     }
 #pragma unroll
-    for (int e = 0; e < 8; ++e) { atomicAdd(&csum[ch + e], s[e]); atomicAdd(&csq[ch + e], q[e]); }
+    for (int e = 0; e < 8; ++e) { psum[myr * C + ch + e] = s[e]; psq[myr * C + ch + e] = q[e]; }
   }
   __syncthreads();
   if (tid < GN_GROUPS) {
     const int cpg = C / GN_GROUPS;
     double a = 0.0, b = 0.0;
-    for (int c = tid * cpg; c < (tid + 1) * cpg; ++c) { a += (double)csum[c]; b += (double)csq[c]; }
+    for (int r = 0; r < rpb; ++r)
+      for (int c = tid * cpg; c < (tid + 1) * cpg; ++c) { a += (double)psum[r * C + c]; b += (double)psq[r * C + c]; }
     double* o = ws + (((long)img * chunks + chunk) * GN_GROUPS + tid) * 2;
     o[0] = a; o[1] = b;
   }
 }
 
-// one block per statistics group-set: (image-group ig) -> images [ig*fpg, (ig+1)*fpg)
-__global__ void gn_finalize_kernel(const double* ws, int chunks, int hw, int C, int fpg, const float* gamma,
-                                   const float* beta, float eps, float* scale, float* shift) {
+// one block per statistics group-set: (image-group ig) -> images [ig*fpg, (ig+1)*fpg).
+// 256 threads = 32 groups x 8 slices; each slice sums a strided subset of the (frame, chunk) partials, then the
+// 8 slices are combined in a fixed order (deterministic).
+__global__ __launch_bounds__(256) void gn_finalize_kernel(const double* ws, int chunks, int hw, int C, int fpg,
+                                                          const float* gamma, const float* beta, float eps,
+                                                          float* scale, float* shift) {
+  __shared__ double s_a[8][GN_GROUPS], s_b[8][GN_GROUPS];
   __shared__ float s_mean[GN_GROUPS], s_rstd[GN_GROUPS];
   const int ig = blockIdx.x, tid = threadIdx.x;
+  const int g = tid & 31, slice = tid >> 5;
+  {
+    double a = 0.0, b = 0.0;
+    const int total = fpg * chunks;
+    const double* base = ws + ((long)ig * fpg * chunks) * GN_GROUPS * 2;
+    for (int i = slice; i < total; i += 8) {
+      const double* o = base + ((long)i * GN_GROUPS + g) * 2;
+      a += o[0]; b += o[1];
+    }
+    s_a[slice][g] = a; s_b[slice][g] = b;
+  }
+  __syncthreads();
   if (tid < GN_GROUPS) {
     double a = 0.0, b = 0.0;
-    for (int f = 0; f < fpg; ++f)
-      for (int ch = 0; ch < chunks; ++ch) {
-        const double* o = ws + ((((long)ig * fpg + f) * chunks + ch) * GN_GROUPS + tid) * 2;
-        a += o[0]; b += o[1];
-      }
+#pragma unroll
+    for (int s = 0; s < 8; ++s) { a += s_a[s][tid]; b += s_b[s][tid]; }
     const double cnt = (double)fpg * hw * (C / GN_GROUPS);
     const double mean = a / cnt;
     double var = b / cnt - mean * mean;
@@ -69,9 +82,9 @@ __global__ void gn_finalize_kernel(const double* ws, int chunks, int hw, int C, 
   __syncthreads();
   const int cpg = C / GN_GROUPS;
   for (int c = tid; c < C; c += blockDim.x) {
-    const int g = c / cpg;
-    const float sc = s_rstd[g] * gamma[c];
-    const float sh = beta[c] - s_mean[g] * sc;
+    const int gg = c / cpg;
+    const float sc = s_rstd[gg] * gamma[c];
+    const float sh = beta[c] - s_mean[gg] * sc;
     for (int f = 0; f < fpg; ++f) {
       scale[((long)ig * fpg + f) * C + c] = sc;
       shift[((long)ig * fpg + f) * C + c] = sh;
@@ -181,7 +194,7 @@ extern "C" int tt_groupnorm_stats(const void* x0, int32_t c0, const void* x1, in
   int threads = cv * rpb; if (threads < GN_GROUPS) threads = GN_GROUPS;
   threads = (threads + 63) / 64 * 64;
   hipStream_t st = (hipStream_t)stream;
-  const size_t lds = (size_t)2 * C * sizeof(float);
+  const size_t lds = (size_t)2 * rpb * C * sizeof(float);
   if (dtype == TT_BF16)
     hipLaunchKernelGGL(gn_partial_kernel<bf16_tag>, dim3(chunks, nimg), dim3(threads), lds, st, (const char*)x0, c0, (const char*)x1, c1, hw, chunks, (double*)ws);
   else

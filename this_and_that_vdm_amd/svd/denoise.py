@@ -25,6 +25,7 @@ class DenoiseLoop:
         self.unet, self.controlnet, self.use_graph = unet, controlnet, use_graph
         self._graph = None
         self._key = None
+        self._static = {}
 
     # ---- request set-up (everything step-invariant)
     def begin(self, latents: torch.Tensor, image_latents: torch.Tensor, encoder_hidden_states: torch.Tensor,
@@ -39,17 +40,25 @@ class DenoiseLoop:
         _, f, _, h, w = latents.shape
         if b not in (1, 2):
             raise NotImplementedError("CFG batch of 1 or 2 (use_instructpix2pix triples it; not built)")
-        self.geom = Geom(b, f, h, w)
-        self.dtype = self.unet._run_dtype()
+        dtype = self.unet._run_dtype()
+        key = (b, f, h, w, dtype, self.controlnet is not None, tuple(encoder_hidden_states.shape), len(timesteps),
+               guidance_scale is not None)
+        if key != self._key:                    # new shapes: new static buffers, new graph
+            self._graph, self._key, self._static = None, key, {}
+        self.geom, self.dtype = Geom(b, f, h, w), dtype
         f32 = lambda t: t.to(device=dev, dtype=torch.float32).contiguous()
-        self.latents = f32(latents).clone().view(f, 4, h, w)
-        self.image_latents = f32(image_latents)
-        self.added_time_ids = f32(added_time_ids)
-        self.guidance = f32(guidance_scale).reshape(-1) if guidance_scale is not None else None
-        self.table = torch.stack([f32(sigmas)[:-1], f32(sigmas)[1:], f32(timesteps)], 1).contiguous()   # [steps, 3]
-        self.cur = torch.zeros(3, dtype=torch.float32, device=dev)                                    # sigma, sigma_next, t
+        sig = f32(sigmas)
+        # static buffers: a captured graph keeps raw pointers, so later requests are COPIED into the same storage
+        self.latents = self._static_set("latents", f32(latents).reshape(f, 4, h, w))
+        self.image_latents = self._static_set("image_latents", f32(image_latents))
+        self.added_time_ids = self._static_set("added_time_ids", f32(added_time_ids))
+        self.guidance = self._static_set("guidance", f32(guidance_scale).reshape(-1)) if guidance_scale is not None else None
+        self.table = self._static_set("table", torch.stack([sig[:-1], sig[1:], f32(timesteps)], 1))       # [steps, 3]
+        self.cur = self._static_set("cur", torch.zeros(3, dtype=torch.float32, device=dev))           # sigma, sigma_next, t
         self.num_steps = self.table.shape[0]
-        self.ctx_unet = self.unet.project_context(encoder_hidden_states.to(dev))
+        ehs = encoder_hidden_states.to(dev)
+        k, vt, s, sp = self.unet.project_context(ehs)
+        self.ctx_unet = (self._static_set("k_unet", k), self._static_set("vt_unet", vt), s, sp)
         self.cond = None
         if self.controlnet is not None:
             if controlnet_cond is None:
@@ -57,14 +66,25 @@ class DenoiseLoop:
             self.controlnet.prepare()
             if self.controlnet._run_dtype() != self.dtype:
                 raise RuntimeError("UNet and ControlNet must run in the same 16-bit dtype inside the fused loop")
-            self.cond = f32(controlnet_cond).view(f, 4, h, w)
-            self.ctx_cn = self.controlnet.project_context(encoder_hidden_states.to(dev))
+            self.cond = self._static_set("cond", f32(controlnet_cond).reshape(f, 4, h, w))
+            k, vt, s, sp = self.controlnet.project_context(ehs)
+            self.ctx_cn = (self._static_set("k_cn", k), self._static_set("vt_cn", vt), s, sp)
             self.cn_scales = self.controlnet._scales(float(conditioning_scale), False, len(self.controlnet.controlnet_down_blocks))
-        key = (b, f, h, w, self.dtype, self.controlnet is not None, encoder_hidden_states.shape[1])
-        if key != self._key:
-            self._graph, self._key = None, key
+            if self._static.setdefault("cn_scales", self.cn_scales) != self.cn_scales:
+                self._graph = None              # the scale is a launch argument baked into the graph
+                self._static["cn_scales"] = self.cn_scales
         self.step_index = 0
         return self
+
+    def _static_set(self, name: str, value: torch.Tensor) -> torch.Tensor:
+        cur = self._static.get(name)
+        if cur is not None and cur.shape == value.shape and cur.dtype == value.dtype:
+            cur.copy_(value)
+            return cur
+        self._static[name] = value.clone()          # never alias the caller's tensor: latents are updated in place
+        if cur is not None:
+            self._graph = None
+        return self._static[name]
 
     # ---- one step's launches (captured once)
     def _launch_step(self):

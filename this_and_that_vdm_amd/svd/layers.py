@@ -217,7 +217,7 @@ class AlphaBlender(nn.Module):
         super().__init__()
         if merge_strategy != "learned_with_images" or switch_spatial_to_temporal_mix:
             raise NotImplementedError(merge_strategy)
-        self.mix_factor = nn.Parameter(torch.Tensor([alpha]))
+        self.mix_factor = nn.Parameter(torch.tensor([float(alpha)]))
 
     def alpha_value(self) -> float:
         return float(torch.sigmoid(self.mix_factor.detach().float()).item())
