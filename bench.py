@@ -101,42 +101,51 @@ def kernel_profile(loop, args):
     return agg
 
 
+CPU_SAMPLE_FRAMES = 2
+
+
 def cpu_baseline(mode, res):
-    """The oracle (CPU restatement of the reference's eager op sequence, fp32) timed on this box's host cores on a
-    bounded sample: one ControlNet + one UNet forward for ONE CFG half (B=1, 14 frames); a step is two halves."""
+    """The oracle (CPU restatement of the reference's eager op sequence, fp32, no hoists) timed on this box's host
+    cores on a BOUNDED sample of the same workload: one ControlNet + one UNet forward of ONE CFG half (B=1) on
+    CPU_SAMPLE_FRAMES of the 14 frames at full latent resolution.  Every op on the path is batched over frames
+    (convs, spatial attention) or runs per pixel over frames (temporal layers), so cost is linear in B*F; a full
+    step = 2 CFG halves x 14 frames -> the sample time is scaled by 2*14/CPU_SAMPLE_FRAMES."""
     from oracle import models as om
     cores = os.cpu_count() or 1
     torch.set_num_threads(cores)
+    torch.set_flush_denormal(True)
     h, w = LATENT[res]
+    f = CPU_SAMPLE_FRAMES
     pat = torch.randn(1 << 20, generator=torch.Generator().manual_seed(0)) * 0.02
 
-    torch.set_flush_denormal(True)
-
-    def cheap_fill(m):          # timing does not depend on the values; avoid a minutes-long RNG init of 2.2 B params
+    def build(ctor):            # meta construction + pattern fill: avoids a minutes-long RNG init of 2.2 B parameters
+        with torch.device("meta"):
+            m = ctor()
+        m = m.to_empty(device="cpu").eval()
         for name, p in m.named_parameters():
             n = p.numel()
             p.data.view(-1).copy_(pat.repeat((n + pat.numel() - 1) // pat.numel())[:n])
             if p.dim() == 1 and name.endswith("weight"):
                 p.data.fill_(1.0)
+        return m
 
     with torch.no_grad():
-        unet = om.UNetSpatioTemporalConditionModel(num_attention_heads=(5, 10, 20, 20), num_frames=FRAMES).eval()
-        cheap_fill(unet)
-        x = torch.randn(1, FRAMES, 8, h, w)
+        unet = build(lambda: om.UNetSpatioTemporalConditionModel(num_attention_heads=(5, 10, 20, 20), num_frames=FRAMES))
+        cn = build(lambda: om.ControlNetModel()) if mode == "vgl" else None
+        x = torch.randn(1, f, 8, h, w)
         ehs = torch.randn(1, CTX_TOKENS, CTX_DIM)
         ati = torch.tensor([[6.0, 200.0, 0.1]])
-        t0 = time.perf_counter()
         down = mid = None
-        if mode == "vgl":
-            cn = om.ControlNetModel().eval()
-            cheap_fill(cn)
-            t0 = time.perf_counter()
-            down, mid = cn(x, 1.0, ehs, ati, controlnet_cond=torch.randn(FRAMES, 4, h, w))
+        t0 = time.perf_counter()
+        if cn is not None:
+            down, mid = cn(x, 1.0, ehs, ati, controlnet_cond=torch.randn(f, 4, h, w))
         unet(x, 1.0, ehs, ati, down_block_additional_residuals=down, mid_block_additional_residual=mid)
-        half = time.perf_counter() - t0
-    return {"value": 1.0 / (2.0 * half), "unit": "denoise-steps/s", "cores": cores, "kind": "port",
-            "sample": f"oracle fp32 eager, 1 {'ControlNet+' if mode == 'vgl' else ''}UNet forward of one CFG half "
-                      f"(B=1, {FRAMES}x4x{h}x{w}) = {half:.1f} s, untimed warm-up none; step = 2 halves (extrapolated)"}
+        sample_s = time.perf_counter() - t0
+    step_s = sample_s * 2 * FRAMES / f
+    return {"value": 1.0 / step_s, "unit": "denoise-steps/s", "cores": cores, "kind": "port",
+            "sample": f"oracle fp32 eager (torch {torch.__version__}, {cores} threads): 1 {'ControlNet+' if cn is not None else ''}"
+                      f"UNet forward, B=1, {f} of {FRAMES} frames at {h}x{w} latents = {sample_s:.1f} s; "
+                      f"step = 2 CFG halves x {FRAMES} frames -> x{2 * FRAMES // f} = {step_s:.0f} s/step"}
 
 
 def main():
