@@ -93,7 +93,7 @@ def kernel_profile(loop, args):
     rec, ops.PROFILE = ops.PROFILE, None
     loop.use_graph = True
     agg = {}
-    for name, flops, e0, e1 in rec:
+    for name, flops, e0, e1, _shape in rec:
         a = agg.setdefault(name, [0, 0.0, 0.0])
         a[0] += 1
         a[1] += flops

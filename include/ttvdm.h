@@ -74,11 +74,19 @@ typedef struct TtGemmArgs {
   void* out; int64_t ldo; int32_t out_f32;
   int32_t out_col_hw, out_col_hwp;     /* if hw>0: column c -> (c/hw)*hwp + c%hw (padded V^T sequences) */
   int32_t dtype;
+  void* ws; int64_t ws_bytes;          /* optional caller-owned scratch for split-K (tt_gemm_ws_bytes); NULL = never split */
 } TtGemmArgs;
 int tt_gemm(const TtGemmArgs* args, tt_stream_t stream);
 /* which BM x BN workgroup tile tt_gemm will use for (m, n): lets a profiler name the kernel instance
  * (gemm_kernel<dtype,BM,BN,2,2,mode>) a launch maps to.  Host-only, no launch. */
 int tt_gemm_plan(const TtGemmArgs* args, int32_t* bm, int32_t* bn);
+/* bytes of fp32 scratch tt_gemm would like for this problem (0 = no split-K planned).  Problems with few output
+ * tiles and a long K (convs at the coarsest UNet levels) are split over K; the slabs are summed in a fixed order,
+ * so results stay bit-reproducible.  Without (enough) workspace the un-split plan runs instead. */
+size_t tt_gemm_ws_bytes(const TtGemmArgs* args);
+/* tuning knob: force tile configuration `cfg` (index into the table in gemm.hip) for every tt_gemm call of this
+ * process; -1 restores the built-in heuristic.  Also settable by the TT_GEMM_CFG environment variable. */
+int tt_gemm_set_tile_override(int32_t cfg);
 
 /* ------------------------------------------------------------------------------------------------
  * tt_attention: softmax(Q K^T / sqrt(d)) V with online softmax on MFMA tiles; replaces

@@ -298,3 +298,51 @@ def test_errors_are_loud(ops):
         ops.gemm(a, torch.zeros(8, 12, dtype=torch.float16, device="cuda"))
     with pytest.raises(RuntimeError, match="HIP device"):
         ops.gemm(torch.zeros(8, 16, dtype=torch.float16), torch.zeros(8, 16, dtype=torch.float16))
+
+
+@pytest.mark.parametrize("cfg", list(range(14)))
+def test_gemm_every_tile_configuration(ops, cfg):
+    """each entry of the tile table in gemm.hip, forced, on a ragged linear and a 2-source conv (bf16)."""
+    from this_and_that_vdm_amd import _lib
+    from this_and_that_vdm_amd.packing import pack_conv3x3
+    lib = _lib.load()
+    dtype = torch.bfloat16
+    try:
+        assert lib.tt_gemm_set_tile_override(cfg) == 0
+        m, n, k = 777, 328, 200
+        a, w = rnd(m, k, dtype=dtype, seed=1), rnd(n, k, dtype=dtype, seed=2, scale=k ** -0.5)
+        bias, res = rnd(n, dtype=torch.float32, seed=3), rnd(m, n, dtype=dtype, seed=5)
+        out = ops.gemm(a.cuda(), w.cuda(), bias=bias.cuda(), residual=res.cuda())
+        close(out, a.float() @ w.float().T + bias + res.float(), dtype, scale=2.0)
+        nimg, c0, c1, cout, h, wd = 2, 72, 40, 168, 9, 13
+        x0, x1 = rnd(nimg, c0, h, wd, dtype=dtype, seed=1), rnd(nimg, c1, h, wd, dtype=dtype, seed=2)
+        wt = rnd(cout, c0 + c1, 3, 3, dtype=dtype, seed=3, scale=0.04)
+        ref = F.conv2d(torch.cat([x0, x1], 1).float(), wt.float(), None, padding=1)
+        t0 = x0.permute(0, 2, 3, 1).reshape(-1, c0).contiguous().cuda()
+        t1 = x1.permute(0, 2, 3, 1).reshape(-1, c1).contiguous().cuda()
+        out = ops.gemm(t0, pack_conv3x3(wt).cuda(), a1=t1, mode=1, conv=(nimg, h, wd, h, wd, 1, 0))
+        close(out, ref.permute(0, 2, 3, 1).reshape(-1, cout), dtype)
+    finally:
+        lib.tt_gemm_set_tile_override(-1)
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+def test_gemm_split_k_is_used_and_exact(ops, dtype):
+    """few tiles + long K -> the planner asks for workspace and splits K; fixed-order slab reduction."""
+    import ctypes as C
+    from this_and_that_vdm_amd import _lib
+    from this_and_that_vdm_amd.packing import pack_conv3x3
+    nimg, cin, cout, h, wd = 4, 640, 256, 7, 9                       # M = 252, K = 5760
+    x = rnd(nimg, cin, h, wd, dtype=dtype, seed=1)
+    wt = rnd(cout, cin, 3, 3, dtype=dtype, seed=2, scale=(9 * cin) ** -0.5)
+    bias, res = rnd(cout, dtype=torch.float32, seed=3), rnd(nimg * h * wd, cout, dtype=dtype, seed=4)
+    g = _lib.TtGemmArgs()
+    g.m, g.n, g.k0, g.mode = nimg * h * wd, cout, cin, 1
+    assert _lib.load().tt_gemm_ws_bytes(C.byref(g)) >= 2 * g.m * g.n * 4
+    tok = x.permute(0, 2, 3, 1).reshape(-1, cin).contiguous().cuda()
+    args = dict(mode=1, conv=(nimg, h, wd, h, wd, 1, 0), bias=bias.cuda(), residual=res.cuda())
+    a = ops.gemm(tok, pack_conv3x3(wt).cuda(), **args)
+    b = ops.gemm(tok, pack_conv3x3(wt).cuda(), **args)
+    assert torch.equal(a, b), "split-K must be bit-reproducible"
+    ref = F.conv2d(x.float(), wt.float(), bias, padding=1).permute(0, 2, 3, 1).reshape(-1, cout) + res.float()
+    close(a, ref, dtype, scale=2.0)

@@ -26,6 +26,7 @@ class TtGemmArgs(C.Structure):
         ("blend", C.c_void_p), ("ld_blend", C.c_int64), ("alpha", C.c_float),
         ("out", C.c_void_p), ("ldo", C.c_int64), ("out_f32", C.c_int32),
         ("out_col_hw", C.c_int32), ("out_col_hwp", C.c_int32), ("dtype", C.c_int32),
+        ("ws", C.c_void_p), ("ws_bytes", C.c_int64),
     ]
 
 
@@ -48,6 +49,8 @@ SIGNATURES = {
     "tt_last_error": (C.c_char_p, []),
     "tt_gemm": (C.c_int, [C.POINTER(TtGemmArgs), _vp]),
     "tt_gemm_plan": (C.c_int, [C.POINTER(TtGemmArgs), C.POINTER(C.c_int32), C.POINTER(C.c_int32)]),
+    "tt_gemm_set_tile_override": (C.c_int, [_i32]),
+    "tt_gemm_ws_bytes": (_sz, [C.POINTER(TtGemmArgs)]),
     "tt_attention": (C.c_int, [C.POINTER(TtAttnArgs), _vp]),
     "tt_temporal_attention": (C.c_int, [_vp, _i64, _vp, _i64, _i32, _i32, _i32, _i32, _i32, _i32, _vp]),
     "tt_groupnorm_ws_bytes": (_sz, [_i32, _i32, _i32]),

@@ -4,14 +4,17 @@
 //
 // One kernel family covers nn.Linear, 1x1 conv, 3x3 conv (stride 1/2, fused nearest-x2 upsample),
 // and the (3,1,1) temporal conv, with up to two channel sources (skip-concat without a concat
-// buffer).  Structure (cdna guide section 5, "minimum 2-phase" form):
-//   * BM x BN x 64 tiles, 4 waves, each wave owns (BM/WGM) x (BN/WGN) as 32x32 MFMA fragments;
-//   * A and W tiles go HBM -> LDS by 16-byte LDS-DMA (global_load_lds), double buffered, one
-//     barrier per K step; out-of-range rows / conv halo / K tails point their lane at a zero page;
+// buffer).  Structure:
+//   * BM x BN x BK tiles, WGM x WGN waves (4 or 8), each wave owns (BM/WGM) x (BN/WGN) as 32x32 MFMA fragments;
+//   * A and W tiles go HBM -> LDS by 16-byte LDS-DMA (global_load_lds) into an NST-deep ring: tile kt+NST-1 is
+//     issued while tile kt is computed, and the wait before tile kt is a COUNTED s_waitcnt vmcnt(G*(NST-2)), so
+//     NST-2 tiles stay in flight across the (raw) s_barrier -- one barrier per K step, no vmcnt(0) in the loop
+//     (cdna guide T3+T4).  Out-of-range rows / conv halo / K tails point their lane at a zero page;
 //   * LDS image is lane-linear with the XOR swizzle applied on the SOURCE chunk and on the read
 //     (conflict-free ds_read_b128, see common.h);
 //   * MFMA operands are swapped (W fragment as the MFMA "A" operand) so each lane ends up with 4
 //     consecutive output columns of one row: 8-byte epilogue loads/stores.
+#include <stdlib.h>
 #include "common.h"
 
 namespace {
@@ -32,16 +35,91 @@ struct GemmP {
   int out_col_hw, out_col_hwp;
   int nk0, nk1, taps, kt_total;     // derived: K steps per source, taps, total K steps
   int tiles_m, tiles_n;
+  int splitk;                       // > 1: block (tile, s) reduces K slice s and writes an fp32 slab to ws
+  float* ws;                        // [splitk][m][n] fp32 partial sums
 };
 
-constexpr int BK = 64;
 
-template <typename Tag, int BM, int BN, int WGM, int WGN, int MODE>
-__global__ __launch_bounds__(256) void gemm_kernel(const GemmP p) {
+// ---- epilogue on 4 consecutive output columns (gn .. gn+3) of row gm
+template <typename Tag>
+__device__ __forceinline__ void epilogue_quad(const GemmP& p, int gm, int gn, float (&v)[4]) {
+  if (p.bias) {
+    const float4 b = *(const float4*)(p.bias + gn);
+    v[0] += b.x; v[1] += b.y; v[2] += b.z; v[3] += b.w;
+  }
+#pragma unroll
+  for (int e = 0; e < 4; ++e) v[e] *= p.acc_scale;
+  if (p.rowvec) {
+    const float4 b = *(const float4*)(p.rowvec + (long)(gm / p.rowvec_rows) * p.ld_rowvec + gn);
+    v[0] += b.x; v[1] += b.y; v[2] += b.z; v[3] += b.w;
+  }
+  if (p.residual) {
+    float r4[4];
+    unpack4<Tag>(*(const uint2*)(p.residual + ((long)gm * p.ld_res + gn) * 2), r4);
+#pragma unroll
+    for (int e = 0; e < 4; ++e) v[e] += r4[e];
+  }
+  if (p.blend) {
+    float r4[4];
+    unpack4<Tag>(*(const uint2*)(p.blend + ((long)gm * p.ld_blend + gn) * 2), r4);
+#pragma unroll
+    for (int e = 0; e < 4; ++e) v[e] = p.alpha * r4[e] + (1.0f - p.alpha) * v[e];
+  }
+  if (p.out_f32) {
+    *(float4*)(p.out + ((long)gm * p.ldo + gn) * 4) = make_float4(v[0], v[1], v[2], v[3]);
+  } else if (p.out_col_hw > 0) {
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      const int c = gn + e;
+      const long oc = (long)(c / p.out_col_hw) * p.out_col_hwp + (c % p.out_col_hw);
+      *(unsigned short*)(p.out + ((long)gm * p.ldo + oc) * 2) = Cvt<Tag>::from_f32(v[e]);
+    }
+  } else {
+    *(uint2*)(p.out + ((long)gm * p.ldo + gn) * 2) = make_uint2(pack2<Tag>(v[0], v[1]), pack2<Tag>(v[2], v[3]));
+  }
+}
+
+// GEGLU: `gn` = packed column of the value quad (gate quad is 8 packed columns further)
+template <typename Tag>
+__device__ __forceinline__ void epilogue_geglu(const GemmP& p, int gm, int gn, float (&val)[4], float (&gate)[4]) {
+  float v[4];
+#pragma unroll
+  for (int e = 0; e < 4; ++e) {
+    float a = val[e], g = gate[e];
+    if (p.bias) { a += p.bias[gn + e]; g += p.bias[gn + 8 + e]; }
+    v[e] = a * gelu_erf_f(g);
+  }
+  const int oc = (gn >> 4) * 8 + (gn & 7);
+  *(uint2*)(p.out + ((long)gm * p.ldo + oc) * 2) = make_uint2(pack2<Tag>(v[0], v[1]), pack2<Tag>(v[2], v[3]));
+}
+
+template <int N> __device__ __forceinline__ void wait_vmcnt() {
+  asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
+}
+// wait until at most `tiles` of the G-load groups issued last are still in flight (tiles <= 3)
+template <int G> __device__ __forceinline__ void wait_tiles(int tiles) {
+  static_assert(3 * G <= 63, "vmcnt field is 6 bits");
+  if (tiles <= 0) wait_vmcnt<0>();
+  else if (tiles == 1) wait_vmcnt<G>();
+  else if (tiles == 2) wait_vmcnt<2 * G>();
+  else wait_vmcnt<3 * G>();
+}
+
+template <typename Tag, int BM, int BN, int BK, int NST, int WGM, int WGN, int MODE>
+__global__ __launch_bounds__(64 * WGM * WGN) void gemm_kernel(const GemmP p) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
-  constexpr int A_BYTES = BM * 128, B_BYTES = BN * 128, STAGE = A_BYTES + B_BYTES;
+  constexpr int NT = 64 * WGM * WGN;                   // threads
+  constexpr int CPR = BK / 8;                          // 16-byte chunks per tile row
+  constexpr int ROWB = BK * 2;
   constexpr int WTM = BM / WGM, WTN = BN / WGN, FM = WTM / 32, FN = WTN / 32;
-  constexpr int AR = BM / 32, BR = BN / 32;           // tile rows staged per thread
+  // 16-byte chunks staged per thread per tile; when the tile does not divide evenly the last pass is padded
+  // (rows >= BM/BN of the LDS image are never read; their lanes load the zero page so every wave issues the
+  // same number of loads and the counted vmcnt stays valid)
+  constexpr int AR = (BM * CPR + NT - 1) / NT, BR = (BN * CPR + NT - 1) / NT;
+  constexpr int A_BYTES = AR * NT * 16, B_BYTES = BR * NT * 16, STAGE = A_BYTES + B_BYTES;
+  constexpr int G = AR + BR;
+  constexpr int RPI = NT / CPR;                        // tile rows covered per staging pass
+  static_assert(NT % CPR == 0 && NST >= 2 && NST <= 5 && WTM % 32 == 0 && WTN % 32 == 0, "tile/threads mismatch");
 
   const int tid = threadIdx.x, lane = tid & 63;
   const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -53,21 +131,26 @@ __global__ __launch_bounds__(256) void gemm_kernel(const GemmP p) {
     const int nwg = gridDim.x, q = nwg >> 3, r = nwg & 7, xcd = bid & 7, idx = bid >> 3;
     bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
   }
+  const int split = p.splitk > 1 ? bid % p.splitk : 0;      // slices of one tile sit next to each other
+  if (p.splitk > 1) bid /= p.splitk;
   const int tile_m = bid / p.tiles_n, tile_n = bid - tile_m * p.tiles_n;
   const int m0 = tile_m * BM, n0 = tile_n * BN;
+  // K-tile range of this block
+  const int kt_lo = (int)((long)p.kt_total * split / p.splitk);
+  const int KT = (int)((long)p.kt_total * (split + 1) / p.splitk) - kt_lo;
 
   // ---- per-thread staging descriptors
-  const int crow = tid >> 3, cchunk = tid & 7;
-  int a_src_chunk[AR];          // source chunk (swizzled) per staged row
-  long a_rowoff0[AR];           // MODE 0: element offset of the row in a0 (a1 uses lda1)
+  const int crow = tid / CPR, cchunk = tid % CPR;
+  int a_src_chunk[AR];
+  long a_rowoff0[AR];
   int a_img[AR], a_y[AR], a_x[AR];
   bool a_valid[AR];
 #pragma unroll
   for (int i = 0; i < AR; ++i) {
-    const int r = i * 32 + crow;
-    a_src_chunk[i] = cchunk ^ tile_swz<8>(r);
+    const int r = i * RPI + crow;
+    a_src_chunk[i] = cchunk ^ tile_swz<CPR>(r);
     const int gm = m0 + r;
-    a_valid[i] = gm < p.m;
+    a_valid[i] = gm < p.m && r < BM;
     const int g = a_valid[i] ? gm : 0;
     if constexpr (MODE == 0) {
       a_rowoff0[i] = (long)g;
@@ -91,23 +174,30 @@ __global__ __launch_bounds__(256) void gemm_kernel(const GemmP p) {
   bool b_valid[BR];
 #pragma unroll
   for (int i = 0; i < BR; ++i) {
-    const int r = i * 32 + crow;
-    b_src_chunk[i] = cchunk ^ tile_swz<8>(r);
+    const int r = i * RPI + crow;
+    b_src_chunk[i] = cchunk ^ tile_swz<CPR>(r);
     const int gn = n0 + r;
-    b_valid[i] = gn < p.n;
+    b_valid[i] = gn < p.n && r < BN;
     b_rowoff[i] = (long)(b_valid[i] ? gn : 0) * p.ldw;
   }
   const char* zero = (const char*)tt_zero_page;
 
   // K-step iterator state for the NEXT tile to stage (uniform)
-  int s_tap = 0, s_src = 0, s_kc = 0;
-  auto stage = [&](int buf) {
+  int s_tap, s_src, s_kc;
+  {
+    const int per_tap = p.nk0 + p.nk1;
+    s_tap = kt_lo / per_tap;
+    const int rem = kt_lo - s_tap * per_tap;
+    s_src = rem >= p.nk0 ? 1 : 0;
+    s_kc = rem - (s_src ? p.nk0 : 0);
+  }
+  auto stage = [&](int slot) {
     const int ksrc = s_src ? p.k1 : p.k0;
     const char* abase = s_src ? p.a1 : p.a0;
     const long lda = s_src ? p.lda1 : p.lda0;
     const int kbase = s_kc * BK;
-    char* lds_a = smem + buf * STAGE + wid * 1024;
-    char* lds_b = smem + buf * STAGE + A_BYTES + wid * 1024;
+    char* lds_a = smem + slot * STAGE + wid * 1024;
+    char* lds_b = smem + slot * STAGE + A_BYTES + wid * 1024;
     int dy = 0, dx = 0;
     if constexpr (MODE == 1) { dy = s_tap / 3 - 1; dx = s_tap - (dy + 1) * 3 - 1; }
 #pragma unroll
@@ -129,7 +219,7 @@ __global__ __launch_bounds__(256) void gemm_kernel(const GemmP p) {
         row = a_rowoff0[i] + (long)(s_tap - 1) * p.hw;
       }
       const char* src = ok ? abase + (row * lda + kk) * 2 : zero;
-      glds16(src, lds_a + i * 4096);
+      glds16(src, lds_a + i * (NT * 16));
     }
     const long wcol = (long)s_tap * (p.k0 + p.k1) + (s_src ? p.k0 : 0) + kbase;
 #pragma unroll
@@ -137,9 +227,8 @@ __global__ __launch_bounds__(256) void gemm_kernel(const GemmP p) {
       const int kk = b_src_chunk[i] * 8;
       const bool ok = b_valid[i] && (kbase + kk) < ksrc;
       const char* src = ok ? p.w + (b_rowoff[i] + wcol + kk) * 2 : zero;
-      glds16(src, lds_b + i * 4096);
+      glds16(src, lds_b + i * (NT * 16));
     }
-    // advance
     if (++s_kc == (s_src ? p.nk1 : p.nk0)) {
       s_kc = 0;
       if (s_src == 0 && p.nk1 > 0) s_src = 1;
@@ -163,25 +252,71 @@ __global__ __launch_bounds__(256) void gemm_kernel(const GemmP p) {
 #pragma unroll
   for (int j = 0; j < FN; ++j) b_lds_row[j] = wc * WTN + j * 32 + l31;
 
-  stage(0);
-  for (int kt = 0; kt < p.kt_total; ++kt) {
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __syncthreads();
-    if (kt + 1 < p.kt_total) stage((kt + 1) & 1);
-    const char* sa = smem + (kt & 1) * STAGE;
+  constexpr int KS = BK / 16;                 // MFMA k sub-steps per tile (even)
+  auto read_frags = [&](const char* sa, int ks, uint4 (&af)[FM], uint4 (&bf)[FN]) {
     const char* sb = sa + A_BYTES;
+    const int chunk = ks * 2 + hi;
 #pragma unroll
-    for (int ks = 0; ks < 4; ++ks) {
-      const int chunk = ks * 2 + hi;
-      uint4 af[FM], bf[FN];
+    for (int i = 0; i < FM; ++i) af[i] = lds_read16(sa, tile_off<CPR>(a_lds_row[i], chunk));
 #pragma unroll
-      for (int i = 0; i < FM; ++i) af[i] = lds_read16(sa, tile_off<8>(a_lds_row[i], chunk));
+    for (int j = 0; j < FN; ++j) bf[j] = lds_read16(sb, tile_off<CPR>(b_lds_row[j], chunk));
+  };
+  auto mma = [&](const uint4 (&af)[FM], const uint4 (&bf)[FN]) {
 #pragma unroll
-      for (int j = 0; j < FN; ++j) bf[j] = lds_read16(sb, tile_off<8>(b_lds_row[j], chunk));
+    for (int i = 0; i < FM; ++i)
 #pragma unroll
-      for (int i = 0; i < FM; ++i)
+      for (int j = 0; j < FN; ++j) acc[i][j] = Cvt<Tag>::mfma32(bf[j], af[i], acc[i][j]);
+  };
+
+  if constexpr (NST == 2) {
+    // plain double buffer: wait tile kt, barrier, issue tile kt+1, compute tile kt
+    stage(0);
+    for (int kt = 0; kt < KT; ++kt) {
+      wait_vmcnt<0>();
+      __builtin_amdgcn_s_barrier();
+      asm volatile("" ::: "memory");
+      if (kt + 1 < KT) stage((kt + 1) & 1);
+      const char* sa = smem + (kt & 1) * STAGE;
 #pragma unroll
-        for (int j = 0; j < FN; ++j) acc[i][j] = Cvt<Tag>::mfma32(bf[j], af[i], acc[i][j]);
+      for (int ks = 0; ks < KS; ++ks) {
+        uint4 af[FM], bf[FN];
+        read_frags(sa, ks, af, bf);
+        mma(af, bf);
+      }
+    }
+  } else {
+    // software pipeline: fragments double-buffered in registers; the wait+barrier for tile kt+1 sits BEFORE the last
+    // MFMA group of tile kt, so the first fragments of tile kt+1 are read (and tile kt+NST-1 is issued) under MFMAs.
+#pragma unroll
+    for (int s = 0; s < NST - 1; ++s)
+      if (s < KT) stage(s);
+    wait_tiles<G>(min(KT - 1, NST - 2));      // tile 0 landed
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
+    uint4 afA[FM], bfA[FN], afB[FM], bfB[FN];
+    read_frags(smem, 0, afA, bfA);
+    int slot = 0, fill = NST - 1;             // slot of tile kt ; slot the next staged tile goes to
+    for (int kt = 0; kt < KT; ++kt) {
+      const char* sa = smem + slot * STAGE;
+      const int nslot = slot + 1 == NST ? 0 : slot + 1;
+#pragma unroll
+      for (int ks = 0; ks < KS; ks += 2) {
+        read_frags(sa, ks + 1, afB, bfB);
+        mma(afA, bfA);
+        if (ks + 2 < KS) {
+          read_frags(sa, ks + 2, afA, bfA);
+        } else if (kt + 1 < KT) {
+          // tile kt+1 must have landed; tiles kt+2 .. min(KT-1, kt+NST-2) may stay in flight
+          wait_tiles<G>(min(KT - 2 - kt, NST - 3));
+          __builtin_amdgcn_s_barrier();       // all waves: tile kt+1 visible, tile kt-1's slot free
+          asm volatile("" ::: "memory");
+          if (kt + NST - 1 < KT) stage(fill);
+          read_frags(smem + nslot * STAGE, 0, afA, bfA);
+        }
+        mma(afB, bfB);
+      }
+      slot = nslot;
+      fill = fill + 1 == NST ? 0 : fill + 1;
     }
   }
 
@@ -190,26 +325,28 @@ __global__ __launch_bounds__(256) void gemm_kernel(const GemmP p) {
   for (int i = 0; i < FM; ++i) {
     const int gm = m0 + wr * WTM + i * 32 + l31;
     if (gm >= p.m) continue;
-    const float* rv = p.rowvec ? p.rowvec + (long)(gm / p.rowvec_rows) * p.ld_rowvec : nullptr;
 #pragma unroll
     for (int j = 0; j < FN; ++j) {
       const int nb = n0 + wc * WTN + j * 32;
+      if (p.splitk > 1) {
+        float* slab = p.ws + ((long)split * p.m + gm) * p.n;
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+          const int gn = nb + 8 * g + 4 * hi;
+          if (gn < p.n) *(float4*)(slab + gn) = make_float4(acc[i][j][g * 4], acc[i][j][g * 4 + 1], acc[i][j][g * 4 + 2], acc[i][j][g * 4 + 3]);
+        }
+        continue;
+      }
       if (p.geglu) {
         // 16-row groups of packed W rows: [8 value | 8 gate]; regs g=0/2 value, g=1/3 gate
 #pragma unroll
         for (int t = 0; t < 2; ++t) {
           const int gn = nb + t * 16 + 4 * hi;          // packed column of the value quad
           if (gn >= p.n) continue;
-          float v[4];
+          float val[4], gate[4];
 #pragma unroll
-          for (int e = 0; e < 4; ++e) {
-            float val = acc[i][j][(2 * t) * 4 + e], gate = acc[i][j][(2 * t + 1) * 4 + e];
-            if (p.bias) { val += p.bias[gn + e]; gate += p.bias[gn + 8 + e]; }
-            v[e] = val * gelu_erf_f(gate);
-          }
-          const int oc = (gn >> 4) * 8 + (gn & 7);
-          uint2 o = make_uint2(pack2<Tag>(v[0], v[1]), pack2<Tag>(v[2], v[3]));
-          *(uint2*)(p.out + ((long)gm * p.ldo + oc) * 2) = o;
+          for (int e = 0; e < 4; ++e) { val[e] = acc[i][j][(2 * t) * 4 + e]; gate[e] = acc[i][j][(2 * t + 1) * 4 + e]; }
+          epilogue_geglu<Tag>(p, gm, gn, val, gate);
         }
         continue;
       }
@@ -220,95 +357,171 @@ __global__ __launch_bounds__(256) void gemm_kernel(const GemmP p) {
         float v[4];
 #pragma unroll
         for (int e = 0; e < 4; ++e) v[e] = acc[i][j][g * 4 + e];
-        if (p.bias) {
-          const float4 b = *(const float4*)(p.bias + gn);
-          v[0] += b.x; v[1] += b.y; v[2] += b.z; v[3] += b.w;
-        }
-#pragma unroll
-        for (int e = 0; e < 4; ++e) v[e] *= p.acc_scale;
-        if (rv) {
-          const float4 b = *(const float4*)(rv + gn);
-          v[0] += b.x; v[1] += b.y; v[2] += b.z; v[3] += b.w;
-        }
-        if (p.residual) {
-          float r4[4];
-          unpack4<Tag>(*(const uint2*)(p.residual + ((long)gm * p.ld_res + gn) * 2), r4);
-#pragma unroll
-          for (int e = 0; e < 4; ++e) v[e] += r4[e];
-        }
-        if (p.blend) {
-          float r4[4];
-          unpack4<Tag>(*(const uint2*)(p.blend + ((long)gm * p.ld_blend + gn) * 2), r4);
-#pragma unroll
-          for (int e = 0; e < 4; ++e) v[e] = p.alpha * r4[e] + (1.0f - p.alpha) * v[e];
-        }
-        if (p.out_f32) {
-          *(float4*)(p.out + ((long)gm * p.ldo + gn) * 4) = make_float4(v[0], v[1], v[2], v[3]);
-        } else if (p.out_col_hw > 0) {
-#pragma unroll
-          for (int e = 0; e < 4; ++e) {
-            const int c = gn + e;
-            const long oc = (long)(c / p.out_col_hw) * p.out_col_hwp + (c % p.out_col_hw);
-            *(unsigned short*)(p.out + ((long)gm * p.ldo + oc) * 2) = Cvt<Tag>::from_f32(v[e]);
-          }
-        } else {
-          *(uint2*)(p.out + ((long)gm * p.ldo + gn) * 2) = make_uint2(pack2<Tag>(v[0], v[1]), pack2<Tag>(v[2], v[3]));
-        }
+        epilogue_quad<Tag>(p, gm, gn, v);
       }
     }
   }
 }
 
-template <typename Tag, int BM, int BN, int WGM, int WGN, int MODE>
+// split-K second pass: sum the fp32 slabs in a fixed order (bit-reproducible) and run the normal epilogue
+template <typename Tag>
+__global__ __launch_bounds__(256) void splitk_epilogue_kernel(const GemmP p) {
+  const long quads = (long)p.m * (p.n >> 2);
+  const int nq = p.n >> 2;
+  for (long q = (long)blockIdx.x * blockDim.x + threadIdx.x; q < quads; q += (long)gridDim.x * blockDim.x) {
+    const int gm = (int)(q / nq), gn = (int)(q - (long)gm * nq) * 4;
+    float4 a = *(const float4*)(p.ws + (long)gm * p.n + gn);
+    for (int s2 = 1; s2 < p.splitk; ++s2) {
+      const float4 b = *(const float4*)(p.ws + ((long)s2 * p.m + gm) * p.n + gn);
+      a.x += b.x; a.y += b.y; a.z += b.z; a.w += b.w;
+    }
+    float v[4] = {a.x, a.y, a.z, a.w};
+    epilogue_quad<Tag>(p, gm, gn, v);
+  }
+}
+
+// ---- configurations: {BM, BN, BK, NST, WGM, WGN}
+template <typename Tag, int BM, int BN, int BK, int NST, int WGM, int WGN, int MODE>
 void launch_mode(const GemmP& p, hipStream_t st) {
-  constexpr size_t lds = 2 * (BM + BN) * 128;
+  constexpr int NT_ = 64 * WGM * WGN, CPR_ = BK / 8;
+  constexpr size_t lds = (size_t)NST * (((BM * CPR_ + NT_ - 1) / NT_) + ((BN * CPR_ + NT_ - 1) / NT_)) * NT_ * 16;
+  static_assert(lds <= 160 * 1024, "LDS ring exceeds 160 KiB");
   static bool attr_done = false;     // one flag per kernel instance: opt in to the full dynamic-LDS size once
   if (!attr_done) {
-    (void)hipFuncSetAttribute((const void*)gemm_kernel<Tag, BM, BN, WGM, WGN, MODE>,
-                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    (void)hipFuncSetAttribute((const void*)gemm_kernel<Tag, BM, BN, BK, NST, WGM, WGN, MODE>,
+                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     attr_done = true;
   }
-  hipLaunchKernelGGL((gemm_kernel<Tag, BM, BN, WGM, WGN, MODE>), dim3(p.tiles_m * p.tiles_n), dim3(256), lds, st, p);
+  hipLaunchKernelGGL((gemm_kernel<Tag, BM, BN, BK, NST, WGM, WGN, MODE>), dim3(p.tiles_m * p.tiles_n * p.splitk),
+                     dim3(64 * WGM * WGN), lds, st, p);
+  if (p.splitk > 1) {
+    long blocks = ((long)p.m * (p.n >> 2) + 255) / 256;
+    if (blocks > 2048) blocks = 2048;
+    hipLaunchKernelGGL(splitk_epilogue_kernel<Tag>, dim3((unsigned)blocks), dim3(256), 0, st, p);
+  }
 }
 
-template <typename Tag, int BM, int BN, int WGM, int WGN>
-int launch_cfg(GemmP& p, hipStream_t st) {
+template <typename Tag, int BM, int BN, int BK, int NST, int WGM, int WGN>
+void launch_cfg(GemmP& p, hipStream_t st) {
   p.tiles_m = ceil_div(p.m, BM);
   p.tiles_n = ceil_div(p.n, BN);
+  p.nk0 = ceil_div(p.k0, BK); p.nk1 = p.k1 ? ceil_div(p.k1, BK) : 0;
+  p.kt_total = p.taps * (p.nk0 + p.nk1);
   switch (p.mode) {
-    case 0: launch_mode<Tag, BM, BN, WGM, WGN, 0>(p, st); break;
-    case 1: launch_mode<Tag, BM, BN, WGM, WGN, 1>(p, st); break;
-    default: launch_mode<Tag, BM, BN, WGM, WGN, 2>(p, st); break;
+    case 0: launch_mode<Tag, BM, BN, BK, NST, WGM, WGN, 0>(p, st); break;
+    case 1: launch_mode<Tag, BM, BN, BK, NST, WGM, WGN, 1>(p, st); break;
+    default: launch_mode<Tag, BM, BN, BK, NST, WGM, WGN, 2>(p, st); break;
   }
-  return 0;
 }
 
-// Tile choice: the largest tile that still gives the 256 CUs about two waves of workgroups.
-void choose_tile(int m, int n, int* bm, int* bn) {
+struct TileCfg { int bm, bn, bk, nst, wgm, wgn; };
+constexpr TileCfg kCfgs[] = {
+  {128, 128, 64, 2, 2, 2},   // 0: round-1 baseline (64 KiB, 2 blocks/CU)
+  {128,  64, 64, 3, 2, 2},   // 1: 72 KiB
+  { 64,  64, 64, 4, 2, 2},   // 2: small problems, deep ring (64 KiB)
+  {256, 128, 32, 3, 4, 2},   // 3: 8 waves, 72 KiB -> 2 blocks/CU
+  {256, 256, 32, 3, 2, 4},   // 4: 8 waves, 96 KiB
+  {256, 256, 32, 4, 2, 4},   // 5: 8 waves, 128 KiB
+  {128, 128, 32, 3, 2, 2},   // 6: 48 KiB -> 3 blocks/CU
+  {128, 128, 32, 4, 2, 2},   // 7: 64 KiB -> 2 blocks/CU
+  {256, 128, 64, 3, 4, 2},   // 8: 8 waves, 144 KiB
+  {128, 128, 64, 3, 2, 2},   // 9: 96 KiB, 1 block/CU
+  {128, 160, 64, 2, 4, 1},   // 10: N = 320 without tile waste, wave tile 32x160, 72 KiB
+  {128, 160, 32, 3, 4, 1},   // 11: 54 KiB
+  {128, 320, 32, 3, 4, 2},   // 12: 8 waves, wave tile 32x160, 84 KiB
+  {256, 320, 32, 3, 4, 2},   // 13: 8 waves, wave tile 64x160, 108 KiB
+};
+constexpr int kNumCfgs = sizeof(kCfgs) / sizeof(kCfgs[0]);
+
+int g_forced_cfg = -2;
+int forced_cfg() {
+  if (g_forced_cfg == -2) { const char* e = getenv("TT_GEMM_CFG"); g_forced_cfg = e ? atoi(e) : -1; }
+  return g_forced_cfg;
+}
+
+int g_forced_split = -2;
+int forced_split() {
+  if (g_forced_split == -2) { const char* e = getenv("TT_GEMM_SPLITK"); g_forced_split = e ? atoi(e) : -1; }
+  return g_forced_split;
+}
+
+// Tile + split-K plan, tuned on MI355X with tools/gemm_bench.py (shapes of the SVD UNet at 256x448 and 512x896):
+//   * N = 320 / 960 (multiple of 160 but not of 128): 128x160 tiles, no column waste;
+//   * tall problems with wide N: 256x128, 8 waves;
+//   * otherwise the largest of 128x128 / 128x64 / 64x64 that still yields ~1.5 workgroups per CU;
+//   * few tiles but a long K (convs at the two coarsest levels): 128x128 tiles with the K loop split over S
+//     workgroups, fp32 slabs reduced in fixed order by a second kernel.
+struct Plan { int cfg, splitk; };
+Plan make_plan(int m, int n, long ktot, bool allow_split) {
+  Plan pl{0, 1};
+  const int f = forced_cfg();
   const long b128 = (long)ceil_div(m, 128) * ceil_div(n, 128);
   const long b12864 = (long)ceil_div(m, 128) * ceil_div(n, 64);
-  if (b128 >= 384) { *bm = 128; *bn = 128; }
-  else if (b12864 >= 384) { *bm = 128; *bn = 64; }
-  else { *bm = 64; *bn = 64; }
+  if (f >= 0 && f < kNumCfgs) pl.cfg = f;
+  else if (n % 160 == 0 && n % 128 != 0 && n <= 960 && m >= 2048) pl.cfg = 10;
+  else if (m >= 8192 && n >= 1024) pl.cfg = 3;
+  else if (m < 2048 && n >= 2560 && n % 160 == 0) pl.cfg = 10;
+  else if (b128 >= 384) pl.cfg = 0;
+  else if (b12864 >= 384) pl.cfg = 1;
+  else pl.cfg = 2;
+  const int fs = forced_split();
+  if (fs >= 1) { pl.splitk = allow_split ? fs : 1; return pl; }
+  const long kt = (ktot + 63) / 64;
+  if (allow_split && f < 0 && b128 < 384 && kt >= 40) {
+    long s = (512 + b128 - 1) / b128;
+    if (s > kt / 8) s = kt / 8;
+    if (s > 16) s = 16;
+    if (s >= 2) { pl.cfg = 0; pl.splitk = (int)s; }
+  }
+  return pl;
 }
 
 template <typename Tag>
-int launch(GemmP& p, hipStream_t st) {
-  int bm, bn;
-  choose_tile(p.m, p.n, &bm, &bn);
-  if (bm == 128 && bn == 128) return launch_cfg<Tag, 128, 128, 2, 2>(p, st);
-  if (bm == 128) return launch_cfg<Tag, 128, 64, 2, 2>(p, st);
-  return launch_cfg<Tag, 64, 64, 2, 2>(p, st);
+void launch(GemmP& p, int cfg, hipStream_t st) {
+  switch (cfg) {
+    case 0: launch_cfg<Tag, 128, 128, 64, 2, 2, 2>(p, st); break;
+    case 1: launch_cfg<Tag, 128, 64, 64, 3, 2, 2>(p, st); break;
+    case 2: launch_cfg<Tag, 64, 64, 64, 4, 2, 2>(p, st); break;
+    case 3: launch_cfg<Tag, 256, 128, 32, 3, 4, 2>(p, st); break;
+    case 4: launch_cfg<Tag, 256, 256, 32, 3, 2, 4>(p, st); break;
+    case 5: launch_cfg<Tag, 256, 256, 32, 4, 2, 4>(p, st); break;
+    case 6: launch_cfg<Tag, 128, 128, 32, 3, 2, 2>(p, st); break;
+    case 7: launch_cfg<Tag, 128, 128, 32, 4, 2, 2>(p, st); break;
+    case 8: launch_cfg<Tag, 256, 128, 64, 3, 4, 2>(p, st); break;
+    case 9: launch_cfg<Tag, 128, 128, 64, 3, 2, 2>(p, st); break;
+    case 10: launch_cfg<Tag, 128, 160, 64, 2, 4, 1>(p, st); break;
+    case 11: launch_cfg<Tag, 128, 160, 32, 3, 4, 1>(p, st); break;
+    case 12: launch_cfg<Tag, 128, 320, 32, 3, 4, 2>(p, st); break;
+    default: launch_cfg<Tag, 256, 320, 32, 3, 4, 2>(p, st); break;
+  }
 }
 
 }  // namespace
 
+extern "C" int tt_gemm_set_tile_override(int32_t cfg) {
+  if (cfg < -1 || cfg >= kNumCfgs) TT_FAIL(TT_EINVAL, "tt_gemm_set_tile_override: cfg %d (valid -1..%d)", cfg, kNumCfgs - 1);
+  g_forced_cfg = cfg;
+  return TT_OK;
+}
+
+static Plan plan_for(const TtGemmArgs* a) {
+  const int taps = a->mode == 1 ? 9 : (a->mode == 2 ? 3 : 1);
+  const bool allow = !a->geglu;
+  return make_plan(a->m, a->n, (long)taps * (a->k0 + a->k1), allow);
+}
+
 extern "C" int tt_gemm_plan(const TtGemmArgs* a, int32_t* bm, int32_t* bn) {
   if (!a || !bm || !bn || a->m <= 0 || a->n <= 0) TT_FAIL(TT_EINVAL, "tt_gemm_plan: bad arguments");
-  int x, y;
-  choose_tile(a->m, a->n, &x, &y);
-  *bm = x; *bn = y;
+  Plan pl = plan_for(a);
+  if (pl.splitk > 1 && (!a->ws || (size_t)a->ws_bytes < (size_t)pl.splitk * a->m * a->n * sizeof(float))) pl = Plan{make_plan(a->m, a->n, 0, false).cfg, 1};
+  *bm = kCfgs[pl.cfg].bm; *bn = kCfgs[pl.cfg].bn;
   return TT_OK;
+}
+
+extern "C" size_t tt_gemm_ws_bytes(const TtGemmArgs* a) {
+  if (!a || a->m <= 0 || a->n <= 0) return 0;
+  const Plan pl = plan_for(a);
+  return pl.splitk > 1 ? (size_t)pl.splitk * a->m * a->n * sizeof(float) : 0;
 }
 
 extern "C" int tt_gemm(const TtGemmArgs* a, tt_stream_t stream) {
@@ -343,10 +556,13 @@ extern "C" int tt_gemm(const TtGemmArgs* a, tt_stream_t stream) {
     if (p.frames <= 0 || p.hw <= 0 || p.m % ((long)p.frames * p.hw)) TT_FAIL(TT_EINVAL, "tt_gemm: tconv geometry");
   }
   p.taps = p.mode == 1 ? 9 : (p.mode == 2 ? 3 : 1);
-  p.nk0 = ceil_div(p.k0, BK); p.nk1 = p.k1 ? ceil_div(p.k1, BK) : 0;
-  p.kt_total = p.taps * (p.nk0 + p.nk1);
+  Plan pl = plan_for(a);
+  if (pl.splitk > 1 && (!a->ws || (size_t)a->ws_bytes < (size_t)pl.splitk * a->m * a->n * sizeof(float)))
+    pl = Plan{make_plan(a->m, a->n, 0, false).cfg, 1};            // no workspace: un-split plan (still correct)
+  p.splitk = pl.splitk;
+  p.ws = (float*)a->ws;
   hipStream_t st = (hipStream_t)stream;
-  if (a->dtype == TT_BF16) launch<bf16_tag>(p, st); else launch<f16_tag>(p, st);
+  if (a->dtype == TT_BF16) launch<bf16_tag>(p, pl.cfg, st); else launch<f16_tag>(p, pl.cfg, st);
   TT_CHECK_LAUNCH("tt_gemm");
   return TT_OK;
 }

@@ -25,11 +25,23 @@ def _prof_begin():
     return e
 
 
-def _prof_end(start, name, flops):
+def _prof_end(start, name, flops, shape=None):
     if start is not None:
         e = torch.cuda.Event(enable_timing=True)
         e.record()
-        PROFILE.append((name, flops, start, e))
+        PROFILE.append((name, flops, start, e, shape))
+
+
+_WS = {}
+
+
+def _workspace(nbytes: int, device) -> torch.Tensor:
+    """Persistent split-K scratch per device (grown on demand; sized during warm-up, so a captured graph keeps a
+    stable pointer).  Launches on one stream are ordered, so every GEMM can share it."""
+    buf = _WS.get(device)
+    if buf is None or buf.numel() < nbytes:
+        buf = _WS[device] = torch.empty(max(nbytes, 64 << 20), dtype=torch.uint8, device=device)
+    return buf
 
 
 def _code(dt: torch.dtype) -> int:
@@ -99,6 +111,10 @@ def gemm(a0: torch.Tensor, w: torch.Tensor, *, a1: Optional[torch.Tensor] = None
     if out_col_pad is not None:
         g.out_col_hw, g.out_col_hwp = out_col_pad
     g.dtype = _code(a0.dtype)
+    need = lib.tt_gemm_ws_bytes(C.byref(g))
+    if need:
+        ws = _workspace(need, a0.device)
+        g.ws, g.ws_bytes = ws.data_ptr(), ws.numel()
     ev = _prof_begin()
     check(lib.tt_gemm(C.byref(g), _stream()), "tt_gemm")
     if ev is not None:
@@ -106,7 +122,8 @@ def gemm(a0: torch.Tensor, w: torch.Tensor, *, a1: Optional[torch.Tensor] = None
         lib.tt_gemm_plan(C.byref(g), C.byref(bm), C.byref(bn))
         taps = 9 if mode == 1 else (3 if mode == 2 else 1)
         tag = "bf16_tag" if g.dtype == TT_BF16 else "f16_tag"
-        _prof_end(ev, f"gemm_kernel<{tag},{bm.value},{bn.value},2,2,{mode}>", 2.0 * g.m * n * taps * (g.k0 + g.k1))
+        _prof_end(ev, f"gemm_kernel<{tag},{bm.value},{bn.value},2,2,{mode}>", 2.0 * g.m * n * taps * (g.k0 + g.k1),
+                  shape=(mode, g.m, n, taps * (g.k0 + g.k1), int(geglu), int(residual is not None)))
     return out
 
 
@@ -125,7 +142,8 @@ def attention(q, k, vt, out, *, nseq, lq, heads, head_dim, mask, lk, k_seq_strid
     if ev is not None:
         tag = "bf16_tag" if a.dtype == TT_BF16 else "f16_tag"
         keys = lk * (ctx_batches if mask == 2 else 1)
-        _prof_end(ev, f"attn_kernel<{tag},{head_dim}>", 4.0 * nseq * heads * lq * (lk if mask != 2 else lk) * head_dim)
+        _prof_end(ev, f"attn_kernel<{tag},{head_dim}>", 4.0 * nseq * heads * lq * lk * head_dim,
+                  shape=("attn", nseq * heads, lq, lk, mask, 0))
     return out
 
 
