@@ -15,6 +15,7 @@
 //   * MFMA operands are swapped (W fragment as the MFMA "A" operand) so each lane ends up with 4
 //     consecutive output columns of one row: 8-byte epilogue loads/stores.
 #include <stdlib.h>
+#include <type_traits>
 #include "common.h"
 
 namespace {
@@ -35,6 +36,7 @@ struct GemmP {
   int out_col_hw, out_col_hwp;
   int nk0, nk1, taps, kt_total;     // derived: K steps per source, taps, total K steps
   int tiles_m, tiles_n;
+  unsigned a0_bytes, a1_bytes, w_bytes;   // extents for the buffer descriptors (< 2 GiB each)
   int splitk;                       // > 1: block (tile, s) reduces K slice s and writes an fp32 slab to ws
   float* ws;                        // [splitk][m][n] fp32 partial sums
 };
@@ -139,48 +141,52 @@ __global__ __launch_bounds__(64 * WGM * WGN) void gemm_kernel(const GemmP p) {
   const int kt_lo = (int)((long)p.kt_total * split / p.splitk);
   const int KT = (int)((long)p.kt_total * (split + 1) / p.splitk) - kt_lo;
 
-  // ---- per-thread staging descriptors
+  // ---- staging: buffer_load ... lds through 128-bit resource descriptors.  Every lane owns a 32-bit byte offset per
+  // staged 16-byte chunk (computed once per tile, or once per conv tap); the K position is a SCALAR offset.  Lanes that
+  // must read zeros (ragged M/N, conv halo, K tail) use an offset beyond num_records: the hardware bounds check returns 0.
+  // This keeps the per-K-step instruction count at ~1 per load (the loop is otherwise instruction-issue bound).
+  constexpr int INV = (int)0x80000000;
+  const __amdgpu_buffer_rsrc_t ra0 = __builtin_amdgcn_make_buffer_rsrc((void*)p.a0, 0, p.a0_bytes, 0x00020000);
+  const __amdgpu_buffer_rsrc_t ra1 = __builtin_amdgcn_make_buffer_rsrc((void*)(p.a1 ? p.a1 : p.a0), 0, p.a1_bytes, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rw = __builtin_amdgcn_make_buffer_rsrc((void*)p.w, 0, p.w_bytes, 0x00020000);
   const int crow = tid / CPR, cchunk = tid % CPR;
-  int a_src_chunk[AR];
-  long a_rowoff0[AR];
+  int a_chunk[AR];              // source chunk (swizzled) per staged row
+  int va0[AR], va1[AR];         // byte offsets into a0 / a1 for the current tap
   int a_img[AR], a_y[AR], a_x[AR];
   bool a_valid[AR];
 #pragma unroll
   for (int i = 0; i < AR; ++i) {
     const int r = i * RPI + crow;
-    a_src_chunk[i] = cchunk ^ tile_swz<CPR>(r);
+    a_chunk[i] = cchunk ^ tile_swz<CPR>(r);
     const int gm = m0 + r;
     a_valid[i] = gm < p.m && r < BM;
     const int g = a_valid[i] ? gm : 0;
+    va0[i] = va1[i] = INV;
+    a_img[i] = a_y[i] = a_x[i] = 0;
     if constexpr (MODE == 0) {
-      a_rowoff0[i] = (long)g;
-      a_img[i] = a_y[i] = a_x[i] = 0;
+      if (a_valid[i]) {
+        va0[i] = (int)(((long)g * p.lda0 + a_chunk[i] * 8) * 2);
+        va1[i] = (int)(((long)g * p.lda1 + a_chunk[i] * 8) * 2);
+      }
     } else if constexpr (MODE == 1) {
       const int hwo = p.hout * p.wout;
       a_img[i] = g / hwo;
       const int rem = g - a_img[i] * hwo;
       a_y[i] = rem / p.wout;
       a_x[i] = rem - a_y[i] * p.wout;
-      a_rowoff0[i] = 0;
     } else {
-      const int bf = g / p.hw;
-      a_img[i] = bf % p.frames;   // frame index
-      a_y[i] = a_x[i] = 0;
-      a_rowoff0[i] = (long)g;
+      a_img[i] = (g / p.hw) % p.frames;   // frame index
+      a_y[i] = g;                         // row
     }
   }
-  int b_src_chunk[BR];
-  long b_rowoff[BR];
-  bool b_valid[BR];
+  int b_chunk[BR], vb[BR];
 #pragma unroll
   for (int i = 0; i < BR; ++i) {
     const int r = i * RPI + crow;
-    b_src_chunk[i] = cchunk ^ tile_swz<CPR>(r);
+    b_chunk[i] = cchunk ^ tile_swz<CPR>(r);
     const int gn = n0 + r;
-    b_valid[i] = gn < p.n && r < BN;
-    b_rowoff[i] = (long)(b_valid[i] ? gn : 0) * p.ldw;
+    vb[i] = (gn < p.n && r < BN) ? (int)(((long)gn * p.ldw + b_chunk[i] * 8) * 2) : INV;
   }
-  const char* zero = (const char*)tt_zero_page;
 
   // K-step iterator state for the NEXT tile to stage (uniform)
   int s_tap, s_src, s_kc;
@@ -191,48 +197,66 @@ __global__ __launch_bounds__(64 * WGM * WGN) void gemm_kernel(const GemmP p) {
     s_src = rem >= p.nk0 ? 1 : 0;
     s_kc = rem - (s_src ? p.nk0 : 0);
   }
+  bool tap_dirty = true;
   auto stage = [&](int slot) {
-    const int ksrc = s_src ? p.k1 : p.k0;
-    const char* abase = s_src ? p.a1 : p.a0;
-    const long lda = s_src ? p.lda1 : p.lda0;
-    const int kbase = s_kc * BK;
+    if constexpr (MODE != 0) {
+      if (tap_dirty) {                       // new tap: refresh the per-lane row offsets (uniform branch)
+        tap_dirty = false;
+#pragma unroll
+        for (int i = 0; i < AR; ++i) {
+          bool ok = a_valid[i];
+          long row;
+          if constexpr (MODE == 1) {
+            const int dy = s_tap / 3 - 1, dx = s_tap - (dy + 1) * 3 - 1;
+            int iy = a_y[i] * p.stride + dy, ix = a_x[i] * p.stride + dx;
+            const int hv = p.upsample ? p.hin * 2 : p.hin, wv = p.upsample ? p.win * 2 : p.win;
+            ok = ok && iy >= 0 && iy < hv && ix >= 0 && ix < wv;
+            if (p.upsample) { iy >>= 1; ix >>= 1; }
+            row = ((long)a_img[i] * p.hin + iy) * p.win + ix;
+          } else {
+            const int f = a_img[i] + s_tap - 1;
+            ok = ok && f >= 0 && f < p.frames;
+            row = (long)a_y[i] + (long)(s_tap - 1) * p.hw;
+          }
+          va0[i] = ok ? (int)((row * p.lda0 + a_chunk[i] * 8) * 2) : INV;
+          va1[i] = ok ? (int)((row * p.lda1 + a_chunk[i] * 8) * 2) : INV;
+        }
+      }
+    }
+    // everything below is wave-uniform except the per-lane offsets; force the scalars into SGPRs so the buffer
+    // instructions get their soffset / descriptor without waterfall loops (cdna guide T20)
+    const int src = __builtin_amdgcn_readfirstlane(s_src);
+    const int ksrc = src ? p.k1 : p.k0;
+    const int kbase = __builtin_amdgcn_readfirstlane(s_kc) * BK;
+    const bool tail = kbase + BK > ksrc;     // only the last K step of a source can have dead chunks
     char* lds_a = smem + slot * STAGE + wid * 1024;
     char* lds_b = smem + slot * STAGE + A_BYTES + wid * 1024;
-    int dy = 0, dx = 0;
-    if constexpr (MODE == 1) { dy = s_tap / 3 - 1; dx = s_tap - (dy + 1) * 3 - 1; }
+    const int soff_a = kbase * 2;
+    const int soff_w = __builtin_amdgcn_readfirstlane(
+        (int)(((long)s_tap * (p.k0 + p.k1) + (src ? p.k0 : 0) + kbase) * 2));
+    auto issue = [&](const __amdgpu_buffer_rsrc_t& ra, const int (&va)[AR], auto has_tail) {
 #pragma unroll
-    for (int i = 0; i < AR; ++i) {
-      const int kk = kbase + a_src_chunk[i] * 8;
-      bool ok = a_valid[i] && kk < ksrc;
-      long row;
-      if constexpr (MODE == 0) {
-        row = a_rowoff0[i];
-      } else if constexpr (MODE == 1) {
-        int iy = a_y[i] * p.stride + dy, ix = a_x[i] * p.stride + dx;
-        const int hv = p.upsample ? p.hin * 2 : p.hin, wv = p.upsample ? p.win * 2 : p.win;
-        ok = ok && iy >= 0 && iy < hv && ix >= 0 && ix < wv;
-        if (p.upsample) { iy >>= 1; ix >>= 1; }
-        row = ((long)a_img[i] * p.hin + iy) * p.win + ix;
-      } else {
-        const int f = a_img[i] + s_tap - 1;
-        ok = ok && f >= 0 && f < p.frames;
-        row = a_rowoff0[i] + (long)(s_tap - 1) * p.hw;
+      for (int i = 0; i < AR; ++i) {
+        int v = va[i];
+        if constexpr (decltype(has_tail)::value) { if (kbase + a_chunk[i] * 8 >= ksrc) v = INV; }
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(ra, (__attribute__((address_space(3))) void*)(lds_a + i * (NT * 16)), 16, v, soff_a, 0, 0);
       }
-      const char* src = ok ? abase + (row * lda + kk) * 2 : zero;
-      glds16(src, lds_a + i * (NT * 16));
-    }
-    const long wcol = (long)s_tap * (p.k0 + p.k1) + (s_src ? p.k0 : 0) + kbase;
 #pragma unroll
-    for (int i = 0; i < BR; ++i) {
-      const int kk = b_src_chunk[i] * 8;
-      const bool ok = b_valid[i] && (kbase + kk) < ksrc;
-      const char* src = ok ? p.w + (b_rowoff[i] + wcol + kk) * 2 : zero;
-      glds16(src, lds_b + i * (NT * 16));
+      for (int i = 0; i < BR; ++i) {
+        int v = vb[i];
+        if constexpr (decltype(has_tail)::value) { if (kbase + b_chunk[i] * 8 >= ksrc) v = INV; }
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rw, (__attribute__((address_space(3))) void*)(lds_b + i * (NT * 16)), 16, v, soff_w, 0, 0);
+      }
+    };
+    if (!tail) {
+      if (!src) issue(ra0, va0, std::false_type{}); else issue(ra1, va1, std::false_type{});
+    } else {
+      if (!src) issue(ra0, va0, std::true_type{}); else issue(ra1, va1, std::true_type{});
     }
     if (++s_kc == (s_src ? p.nk1 : p.nk0)) {
       s_kc = 0;
       if (s_src == 0 && p.nk1 > 0) s_src = 1;
-      else { s_src = 0; ++s_tap; }
+      else { s_src = 0; ++s_tap; tap_dirty = true; }
     }
   };
 
@@ -556,6 +580,14 @@ extern "C" int tt_gemm(const TtGemmArgs* a, tt_stream_t stream) {
     if (p.frames <= 0 || p.hw <= 0 || p.m % ((long)p.frames * p.hw)) TT_FAIL(TT_EINVAL, "tt_gemm: tconv geometry");
   }
   p.taps = p.mode == 1 ? 9 : (p.mode == 2 ? 3 : 1);
+  {
+    const long rows = p.mode == 1 ? (long)p.nimg * p.hin * p.win : (long)p.m;
+    const long a0b = ((rows - 1) * p.lda0 + p.k0) * 2, a1b = p.k1 ? ((rows - 1) * p.lda1 + p.k1) * 2 : 16;
+    const long wb = ((long)(p.n - 1) * p.ldw + (long)p.taps * (p.k0 + p.k1)) * 2;
+    if (a0b >= (1L << 31) || a1b >= (1L << 31) || wb >= (1L << 31))
+      TT_FAIL(TT_EUNSUPPORTED, "tt_gemm: operand larger than 2 GiB (32-bit buffer offsets)");
+    p.a0_bytes = (unsigned)a0b; p.a1_bytes = (unsigned)a1b; p.w_bytes = (unsigned)wb;
+  }
   Plan pl = plan_for(a);
   if (pl.splitk > 1 && (!a->ws || (size_t)a->ws_bytes < (size_t)pl.splitk * a->m * a->n * sizeof(float)))
     pl = Plan{make_plan(a->m, a->n, 0, false).cfg, 1};            // no workspace: un-split plan (still correct)
