@@ -20,8 +20,9 @@ struct AttnP {
   char* out; long ldo;
   int nseq, lq, heads;
   int mask, lk, k_seq_stride, v_seq_stride, frames, ctx_batches;
-  int k_rows_total;     // rows of k that exist (for the zero-page predicate)
+  int k_rows_total;     // rows of k that exist
   long vt_cols_total;   // columns of vt that exist
+  unsigned k_bytes, vt_bytes;   // extents for the buffer descriptors
   float scale_log2e;
 };
 
@@ -64,25 +65,46 @@ __global__ __launch_bounds__(256) void attn_kernel(const AttnP p) {
   int my_ctx = 0;
   if (p.mask == 2) my_ctx = (int)((((long)(seq / p.frames)) * p.lq + (qok ? qrow : 0)) % p.ctx_batches);
 
+  // staging by buffer_load ... lds: per-lane 32-bit byte offsets computed once, the tile position is a scalar offset,
+  // out-of-range rows/columns land beyond num_records and read as zeros (same scheme as gemm.hip).
+  constexpr int INV = (int)0x80000000;
+  const __amdgpu_buffer_rsrc_t rk = __builtin_amdgcn_make_buffer_rsrc((void*)p.k, 0, p.k_bytes, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rv = __builtin_amdgcn_make_buffer_rsrc((void*)p.vt, 0, p.vt_bytes, 0x00020000);
+  int kvo[KPT], kr[KPT], vvo[VPT], vc[VPT];
+#pragma unroll
+  for (int i = 0; i < KPT; ++i) {
+    const int slot = i * 256 + tid;
+    const int r = slot / KCPR, c = (slot % KCPR) ^ tile_swz<KCPR>(r);
+    kr[i] = r;
+    kvo[i] = (int)((((long)kbase + r) * p.ldk + head * D + c * 8) * 2);
+  }
+#pragma unroll
+  for (int i = 0; i < VPT; ++i) {
+    const int slot = i * 256 + tid;
+    const int r = slot >> 3, c = (slot & 7) ^ tile_swz<8>(r);
+    vc[i] = c * 8;
+    vvo[i] = (int)(((long)(head * D + r) * p.ldvt + vbase + c * 8) * 2);
+  }
+  const int k_rows_left = p.k_rows_total - kbase;            // rows of K that exist from kbase on
+  const long v_cols_left = p.vt_cols_total - vbase;
   auto stage = [&](int buf, int tile) {
     const int j0 = tile * KB;
     char* lk_ = smem + buf * STAGE + wid * 1024;
     char* lv_ = smem + buf * STAGE + K_BYTES + wid * 1024;
+    const int soff_k = __builtin_amdgcn_readfirstlane((int)((long)j0 * p.ldk * 2));
+    const int soff_v = j0 * 2;
+    const bool edge = j0 + KB > k_rows_left || j0 + KB > v_cols_left;    // uniform: only the last tile(s)
 #pragma unroll
     for (int i = 0; i < KPT; ++i) {
-      const int slot = i * 256 + tid;
-      const int r = slot / KCPR, c = (slot % KCPR) ^ tile_swz<KCPR>(r);
-      const long krow = (long)kbase + j0 + r;
-      const bool ok = krow < p.k_rows_total;
-      glds16(ok ? p.k + (krow * p.ldk + head * D + c * 8) * 2 : zero, lk_ + i * 4096);
+      int v = kvo[i];
+      if (edge && j0 + kr[i] >= k_rows_left) v = INV;
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(rk, (__attribute__((address_space(3))) void*)(lk_ + i * 4096), 16, v, soff_k, 0, 0);
     }
 #pragma unroll
     for (int i = 0; i < VPT; ++i) {
-      const int slot = i * 256 + tid;
-      const int r = slot >> 3, c = (slot & 7) ^ tile_swz<8>(r);
-      const long col = (long)vbase + j0 + c * 8;
-      const bool ok = col < p.vt_cols_total;
-      glds16(ok ? p.vt + ((long)(head * D + r) * p.ldvt + col) * 2 : zero, lv_ + i * 4096);
+      int v = vvo[i];
+      if (edge && j0 + vc[i] >= v_cols_left) v = INV;
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(rv, (__attribute__((address_space(3))) void*)(lv_ + i * 4096), 16, v, soff_v, 0, 0);
     }
   };
 
@@ -116,23 +138,29 @@ __global__ __launch_bounds__(256) void attn_kernel(const AttnP p) {
         s[kb] = Cvt<Tag>::mfma32(kf, qf[ds], s[kb]);
       }
     }
-    // ---- mask + online softmax (lane: one query, keys j0 + kb*32 + hi*16 + r)
+    // ---- mask + online softmax (lane: one query, keys j0 + kb*32 + hi*16 + r).  Raw scores stay unscaled: the
+    // 1/sqrt(d)*log2(e) factor c is folded into the exponent, p = exp2(s*c - m*c), one FMA per score.
     const int j0 = t * KB;
-    float mx = -INFINITY;
+    const bool need_mask = p.mask == 2 || j0 + KB > p.lk;       // uniform: interior tiles of masks 0/1 skip the compares
+    if (need_mask) {
+#pragma unroll
+      for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int j = j0 + kb * 32 + hi * 16 + r;
+          bool ok;
+          if (p.mask == 2) { const int cb = j / p.k_seq_stride; ok = (j - cb * p.k_seq_stride) < p.lk && cb == my_ctx; }
+          else ok = j < p.lk;
+          if (!ok) s[kb][r] = -INFINITY;
+        }
+    }
+    float mx = s[0][0];
 #pragma unroll
     for (int kb = 0; kb < 2; ++kb)
 #pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        const int j = j0 + kb * 32 + hi * 16 + r;
-        bool ok;
-        if (p.mask == 2) { const int cb = j / p.k_seq_stride; ok = (j - cb * p.k_seq_stride) < p.lk && cb == my_ctx; }
-        else ok = j < p.lk;
-        const float v = ok ? s[kb][r] * p.scale_log2e : -INFINITY;
-        s[kb][r] = v;
-        mx = fmaxf(mx, v);
-      }
+      for (int r = 0; r < 16; ++r) mx = fmaxf(mx, s[kb][r]);
     mx = fmaxf(mx, __shfl_xor(mx, 32));
-    const float m_new = fmaxf(m_run, mx);
+    const float m_new = fmaxf(m_run, mx * p.scale_log2e);       // running max of the SCALED scores (finite: starts at -1e30)
     const float alpha = exp2f(m_run - m_new);
     m_run = m_new;
     float psum = 0.f;
@@ -143,14 +171,16 @@ __global__ __launch_bounds__(256) void attn_kernel(const AttnP p) {
       for (int h = 0; h < 2; ++h) {
         float e[8];
 #pragma unroll
-        for (int r = 0; r < 8; ++r) { e[r] = exp2f(s[kb][h * 8 + r] - m_new); psum += e[r]; }
+        for (int r = 0; r < 8; ++r) { e[r] = exp2f(fmaf(s[kb][h * 8 + r], p.scale_log2e, -m_new)); psum += e[r]; }
         pf[kb * 2 + h] = pack8<Tag>(e);
       }
     l_run = l_run * alpha + psum;
+    if (__any(alpha != 1.0f)) {                                 // the running max moved for some query of this wave
 #pragma unroll
-    for (int i = 0; i < DB; ++i)
+      for (int i = 0; i < DB; ++i)
 #pragma unroll
-      for (int r = 0; r < 16; ++r) o[i][r] *= alpha;
+        for (int r = 0; r < 16; ++r) o[i][r] *= alpha;
+    }
     // ---- O^T += Vt_tile * P^T : k-slot (hi, e) of step (kb,h) is key kb*32 + 16*hi + 8*h + e
 #pragma unroll
     for (int db = 0; db < DB; ++db) {
@@ -323,6 +353,12 @@ extern "C" int tt_attention(const TtAttnArgs* a, tt_stream_t stream) {
   p.k_rows_total = nctx * a->k_seq_stride;
   p.vt_cols_total = (long)nctx * a->v_seq_stride;
   if (p.vt_cols_total > a->ldvt) TT_FAIL(TT_EINVAL, "tt_attention: ldvt smaller than the key columns");
+  {
+    const long kb = ((long)(p.k_rows_total - 1) * a->ldk + (long)a->heads * a->head_dim) * 2;
+    const long vb = ((long)(a->heads * a->head_dim - 1) * a->ldvt + p.vt_cols_total) * 2;
+    if (kb >= (1L << 31) || vb >= (1L << 31)) TT_FAIL(TT_EUNSUPPORTED, "tt_attention: K or V^T larger than 2 GiB");
+    p.k_bytes = (unsigned)kb; p.vt_bytes = (unsigned)vb;
+  }
   p.scale_log2e = 1.4426950408889634f / sqrtf((float)a->head_dim);
   hipStream_t st = (hipStream_t)stream;
   if (a->dtype == TT_BF16) { if (a->head_dim == 64) launch_attn<bf16_tag, 64>(p, st); else launch_attn<bf16_tag, 128>(p, st); }

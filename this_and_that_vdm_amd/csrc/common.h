@@ -27,11 +27,8 @@ void tt_set_error(const char* fmt, ...);
 template <typename Tag> struct Cvt;
 template <> struct Cvt<bf16_tag> {
   static __device__ __forceinline__ float to_f32(unsigned short b) { return __uint_as_float(((unsigned)b) << 16); }
-  static __device__ __forceinline__ unsigned short from_f32(float f) {  // round-to-nearest-even
-    unsigned u = __float_as_uint(f);
-    if ((u & 0x7fffffffu) > 0x7f800000u) return (unsigned short)((u >> 16) | 0x40);
-    u += 0x7fffu + ((u >> 16) & 1u);
-    return (unsigned short)(u >> 16);
+  static __device__ __forceinline__ unsigned short from_f32(float f) {  // round-to-nearest-even (v_cvt_pk_bf16_f32)
+    return __builtin_bit_cast(unsigned short, (__bf16)f);
   }
   static __device__ __forceinline__ f32x16_t mfma32(uint4 a, uint4 b, f32x16_t c) {
     return __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8_t, a), __builtin_bit_cast(bf16x8_t, b), c, 0, 0, 0);
@@ -45,8 +42,16 @@ template <> struct Cvt<f16_tag> {
   }
 };
 
-template <typename Tag> __device__ __forceinline__ unsigned pack2(float lo, float hi) {
-  return (unsigned)Cvt<Tag>::from_f32(lo) | ((unsigned)Cvt<Tag>::from_f32(hi) << 16);
+// two floats -> one dword of two 16-bit values, one instruction (v_cvt_pk_bf16_f32 / v_cvt_pk_f16_f32, RNE)
+typedef __attribute__((ext_vector_type(2))) float f32x2_t;
+typedef __attribute__((ext_vector_type(2))) __bf16 bf16x2_t;
+typedef __attribute__((ext_vector_type(2))) _Float16 f16x2_t;
+template <typename Tag> __device__ __forceinline__ unsigned pack2(float lo, float hi);
+template <> __device__ __forceinline__ unsigned pack2<bf16_tag>(float lo, float hi) {
+  return __builtin_bit_cast(unsigned, __builtin_convertvector((f32x2_t){lo, hi}, bf16x2_t));
+}
+template <> __device__ __forceinline__ unsigned pack2<f16_tag>(float lo, float hi) {
+  return __builtin_bit_cast(unsigned, __builtin_convertvector((f32x2_t){lo, hi}, f16x2_t));
 }
 template <typename Tag> __device__ __forceinline__ void unpack8(const uint4& v, float* f) {
   const unsigned w[4] = {v.x, v.y, v.z, v.w};
