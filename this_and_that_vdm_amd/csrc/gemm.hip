@@ -344,7 +344,95 @@ __global__ __launch_bounds__(64 * WGM * WGN) void gemm_kernel(const GemmP p) {
     }
   }
 
-  // ---- epilogue: lane holds row m = .. + l31, columns n = .. + 8g + 4hi + {0..3} for g = 0..3
+  // ---- epilogue.  The MFMA layout gives a lane row m = .. + l31 and columns n = .. + 8g + 4hi + {0..3}: stored
+  // directly, one instruction would touch 32 rows x 16 bytes.  Instead each wave transposes its accumulators through a
+  // private LDS strip (fp32, 32 rows x 64 columns at a time) and re-reads them so that 16 consecutive lanes cover 64
+  // consecutive columns of one row: every residual/blend load and every store instruction then covers 4 rows x 128
+  // contiguous bytes.  The arithmetic (fp32, same order) is unchanged.
+  const bool direct = p.splitk > 1 || p.out_col_hw > 0;
+  if (!direct) {
+    __syncthreads();                                   // all waves are done with the operand ring
+    constexpr int ROWE = 64 * 4 + 16;                  // strip row: 64 fp32 + pad (bank spread)
+    char* ebuf = smem + wid * (32 * ROWE);
+    static_assert(WGM * WGN * 32 * ROWE <= NST * STAGE, "epilogue strip does not fit the ring");
+#pragma unroll
+    for (int i = 0; i < FM; ++i) {
+      const int mb = m0 + wr * WTM + i * 32;
+      if (!p.geglu) {
+#pragma unroll
+        for (int jc = 0; jc < FN; jc += 2) {
+          constexpr int QMAX = 16;
+          const int nfr = (jc + 1 < FN) ? 2 : 1;       // fragments in this chunk (compile-time after unrolling)
+#pragma unroll
+          for (int jj = 0; jj < 2; ++jj) {
+            if (jc + jj < FN) {
+#pragma unroll
+              for (int g = 0; g < 4; ++g)
+                *(float4*)(ebuf + l31 * ROWE + (jj * 32 + 8 * g + 4 * hi) * 4) =
+                    make_float4(acc[i][jc + jj][g * 4], acc[i][jc + jj][g * 4 + 1], acc[i][jc + jj][g * 4 + 2], acc[i][jc + jj][g * 4 + 3]);
+            }
+          }
+          const int q_per_row = nfr * 8;               // 4-column quads per strip row
+          const int rows_per_pass = 64 / q_per_row;
+          const int qq = lane % q_per_row, rr = lane / q_per_row;
+          const int gn = n0 + wc * WTN + jc * 32 + qq * 4;
+#pragma unroll
+          for (int pass = 0; pass < 32 * QMAX / 64; ++pass) {
+            if (pass * rows_per_pass < 32) {
+              const int r = pass * rows_per_pass + rr;
+              const float4 t = *(const float4*)(ebuf + r * ROWE + qq * 16);
+              const int gm = mb + r;
+              if (gm < p.m && gn < p.n) {
+                float v[4] = {t.x, t.y, t.z, t.w};
+                epilogue_quad<Tag>(p, gm, gn, v);
+              }
+            }
+          }
+        }
+      } else {
+        // GEGLU: value/gate pairs are lane-local (regs g=0/2 value, g=1/3 gate); gelu in registers, then the 16
+        // output columns of each fragment go through the strip: 2 fragments -> 32 output columns = 64 bytes per row.
+#pragma unroll
+        for (int jc = 0; jc < FN; jc += 2) {
+          const int nfr = (jc + 1 < FN) ? 2 : 1;
+#pragma unroll
+          for (int jj = 0; jj < 2; ++jj) {
+            if (jc + jj < FN) {
+              const int nb = n0 + wc * WTN + (jc + jj) * 32;
+#pragma unroll
+              for (int tt = 0; tt < 2; ++tt) {
+                const int gnp = nb + tt * 16 + 4 * hi;            // packed column of the value quad
+                float v[4];
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                  float a = acc[i][jc + jj][(2 * tt) * 4 + e], g2 = acc[i][jc + jj][(2 * tt + 1) * 4 + e];
+                  if (p.bias && gnp < p.n) { a += p.bias[gnp + e]; g2 += p.bias[gnp + 8 + e]; }
+                  v[e] = a * gelu_erf_f(g2);
+                }
+                *(float4*)(ebuf + l31 * ROWE + (jj * 16 + tt * 8 + 4 * hi) * 4) = make_float4(v[0], v[1], v[2], v[3]);
+              }
+            }
+          }
+          const int q_per_row = nfr * 4;               // output quads per strip row (16 output columns per fragment)
+          const int rows_per_pass = 64 / q_per_row;
+          const int qq = lane % q_per_row, rr = lane / q_per_row;
+          const int oc = ((n0 + wc * WTN + jc * 32) >> 1) + qq * 4;     // output column
+#pragma unroll
+          for (int pass = 0; pass < 4; ++pass) {
+            if (pass * rows_per_pass < 32) {
+              const int r = pass * rows_per_pass + rr;
+              const float4 t = *(const float4*)(ebuf + r * ROWE + qq * 16);
+              const int gm = mb + r;
+              if (gm < p.m && oc * 2 < p.n)
+                *(uint2*)(p.out + ((long)gm * p.ldo + oc) * 2) = make_uint2(pack2<Tag>(t.x, t.y), pack2<Tag>(t.z, t.w));
+            }
+          }
+        }
+      }
+    }
+    return;
+  }
+  // direct path: split-K slabs and the padded transposed output
 #pragma unroll
   for (int i = 0; i < FM; ++i) {
     const int gm = m0 + wr * WTM + i * 32 + l31;
@@ -358,19 +446,6 @@ __global__ __launch_bounds__(64 * WGM * WGN) void gemm_kernel(const GemmP p) {
         for (int g = 0; g < 4; ++g) {
           const int gn = nb + 8 * g + 4 * hi;
           if (gn < p.n) *(float4*)(slab + gn) = make_float4(acc[i][j][g * 4], acc[i][j][g * 4 + 1], acc[i][j][g * 4 + 2], acc[i][j][g * 4 + 3]);
-        }
-        continue;
-      }
-      if (p.geglu) {
-        // 16-row groups of packed W rows: [8 value | 8 gate]; regs g=0/2 value, g=1/3 gate
-#pragma unroll
-        for (int t = 0; t < 2; ++t) {
-          const int gn = nb + t * 16 + 4 * hi;          // packed column of the value quad
-          if (gn >= p.n) continue;
-          float val[4], gate[4];
-#pragma unroll
-          for (int e = 0; e < 4; ++e) { val[e] = acc[i][j][(2 * t) * 4 + e]; gate[e] = acc[i][j][(2 * t + 1) * 4 + e]; }
-          epilogue_geglu<Tag>(p, gm, gn, val, gate);
         }
         continue;
       }
