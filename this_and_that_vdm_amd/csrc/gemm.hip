@@ -43,8 +43,9 @@ struct GemmP {
 
 
 // ---- epilogue on 4 consecutive output columns (gn .. gn+3) of row gm
-template <typename Tag>
-__device__ __forceinline__ void epilogue_quad(const GemmP& p, int gm, int gn, float (&v)[4]) {
+template <typename Tag, bool PRELOADED = false>
+__device__ __forceinline__ void epilogue_quad(const GemmP& p, int gm, int gn, float (&v)[4], uint2 res_pre = make_uint2(0, 0),
+                                              uint2 blend_pre = make_uint2(0, 0)) {
   if (p.bias) {
     const float4 b = *(const float4*)(p.bias + gn);
     v[0] += b.x; v[1] += b.y; v[2] += b.z; v[3] += b.w;
@@ -57,13 +58,13 @@ __device__ __forceinline__ void epilogue_quad(const GemmP& p, int gm, int gn, fl
   }
   if (p.residual) {
     float r4[4];
-    unpack4<Tag>(*(const uint2*)(p.residual + ((long)gm * p.ld_res + gn) * 2), r4);
+    unpack4<Tag>(PRELOADED ? res_pre : *(const uint2*)(p.residual + ((long)gm * p.ld_res + gn) * 2), r4);
 #pragma unroll
     for (int e = 0; e < 4; ++e) v[e] += r4[e];
   }
   if (p.blend) {
     float r4[4];
-    unpack4<Tag>(*(const uint2*)(p.blend + ((long)gm * p.ld_blend + gn) * 2), r4);
+    unpack4<Tag>(PRELOADED ? blend_pre : *(const uint2*)(p.blend + ((long)gm * p.ld_blend + gn) * 2), r4);
 #pragma unroll
     for (int e = 0; e < 4; ++e) v[e] = p.alpha * r4[e] + (1.0f - p.alpha) * v[e];
   }
@@ -351,6 +352,31 @@ __global__ __launch_bounds__(64 * WGM * WGN) void gemm_kernel(const GemmP p) {
   // contiguous bytes.  The arithmetic (fp32, same order) is unchanged.
   const bool direct = p.splitk > 1 || p.out_col_hw > 0;
   if (!direct) {
+    constexpr int NCH = (FN + 1) / 2;                  // 64-column chunks per fragment row
+    // residual / blend operands of every (row, quad) this lane will finish: issued as ONE batch up front so their
+    // latency overlaps the barrier and the LDS transposition instead of serialising pass by pass
+    // (the AlphaBlender source is usually the residual tensor itself -- temporal ResBlock -- and then shares the
+    // preloaded value; a distinct blend tensor is read in-pass to keep the register budget at 2 waves per SIMD)
+    uint2 resv[FM][NCH][8];
+    const bool blend_is_res = p.blend && p.blend == p.residual && p.ld_blend == p.ld_res;
+    if (!p.geglu && p.residual) {
+#pragma unroll
+      for (int i = 0; i < FM; ++i)
+#pragma unroll
+        for (int c = 0; c < NCH; ++c) {
+          const int nfr = (2 * c + 1 < FN) ? 2 : 1;
+          const int q_per_row = nfr * 8, rows_per_pass = 64 / q_per_row;
+          const int gn = n0 + wc * WTN + c * 64 + (lane % q_per_row) * 4;
+#pragma unroll
+          for (int pass = 0; pass < 8; ++pass) {
+            resv[i][c][pass] = make_uint2(0, 0);
+            if (pass * rows_per_pass < 32) {
+              const int gm = m0 + wr * WTM + i * 32 + pass * rows_per_pass + lane / q_per_row;
+              if (gm < p.m && gn < p.n) resv[i][c][pass] = *(const uint2*)(p.residual + ((long)gm * p.ld_res + gn) * 2);
+            }
+          }
+        }
+    }
     __syncthreads();                                   // all waves are done with the operand ring
     constexpr int ROWE = 64 * 4 + 16;                  // strip row: 64 fp32 + pad (bank spread)
     char* ebuf = smem + wid * (32 * ROWE);
@@ -384,7 +410,9 @@ __global__ __launch_bounds__(64 * WGM * WGN) void gemm_kernel(const GemmP p) {
               const int gm = mb + r;
               if (gm < p.m && gn < p.n) {
                 float v[4] = {t.x, t.y, t.z, t.w};
-                epilogue_quad<Tag>(p, gm, gn, v);
+                const uint2 rq = resv[i][jc / 2][pass];
+                const uint2 bq = (p.blend && !blend_is_res) ? *(const uint2*)(p.blend + ((long)gm * p.ld_blend + gn) * 2) : rq;
+                epilogue_quad<Tag, true>(p, gm, gn, v, rq, bq);
               }
             }
           }
