@@ -29,7 +29,10 @@ struct AttnP {
 constexpr int QB = 128;   // queries per block
 constexpr int KB = 64;    // keys per tile
 
-template <typename Tag, int D>
+// raw v_exp_f32: inputs here are <= 0 or -inf (exp2(-inf) = 0), no denormal/range fix-ups needed
+__device__ __forceinline__ float fast_exp2(float x) { return __builtin_amdgcn_exp2f(x); }
+
+template <typename Tag, int D, int MASK>
 __global__ __launch_bounds__(256) void attn_kernel(const AttnP p) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   constexpr int KCPR = D / 8;                 // 16-B chunks per K-tile row (row = key, D elements)
@@ -48,8 +51,8 @@ __global__ __launch_bounds__(256) void attn_kernel(const AttnP p) {
 
   // ---- which keys does this sequence see
   int kbase, vbase, ntiles;
-  if (p.mask == 0) { kbase = seq * p.k_seq_stride; vbase = seq * p.v_seq_stride; ntiles = (p.lk + KB - 1) / KB; }
-  else if (p.mask == 1) { const int b = seq / p.frames; kbase = b * p.k_seq_stride; vbase = b * p.v_seq_stride; ntiles = (p.lk + KB - 1) / KB; }
+  if (MASK == 0) { kbase = seq * p.k_seq_stride; vbase = seq * p.v_seq_stride; ntiles = (p.lk + KB - 1) / KB; }
+  else if (MASK == 1) { const int b = seq / p.frames; kbase = b * p.k_seq_stride; vbase = b * p.v_seq_stride; ntiles = (p.lk + KB - 1) / KB; }
   else { kbase = 0; vbase = 0; ntiles = (p.ctx_batches * p.k_seq_stride + KB - 1) / KB; }
 
   // ---- Q^T fragments straight from global: lane (query l31) holds d = ds*16 + hi*8 .. +8
@@ -63,7 +66,7 @@ __global__ __launch_bounds__(256) void attn_kernel(const AttnP p) {
   }
   // temporal-cross pairing (reference quirk Q3): the context this query may look at
   int my_ctx = 0;
-  if (p.mask == 2) my_ctx = (int)((((long)(seq / p.frames)) * p.lq + (qok ? qrow : 0)) % p.ctx_batches);
+  if (MASK == 2) my_ctx = (int)((((long)(seq / p.frames)) * p.lq + (qok ? qrow : 0)) % p.ctx_batches);
 
   // staging by buffer_load ... lds: per-lane 32-bit byte offsets computed once, the tile position is a scalar offset,
   // out-of-range rows/columns land beyond num_records and read as zeros (same scheme as gemm.hip).
@@ -141,7 +144,7 @@ __global__ __launch_bounds__(256) void attn_kernel(const AttnP p) {
     // ---- mask + online softmax (lane: one query, keys j0 + kb*32 + hi*16 + r).  Raw scores stay unscaled: the
     // 1/sqrt(d)*log2(e) factor c is folded into the exponent, p = exp2(s*c - m*c), one FMA per score.
     const int j0 = t * KB;
-    const bool need_mask = p.mask == 2 || j0 + KB > p.lk;       // uniform: interior tiles of masks 0/1 skip the compares
+    const bool need_mask = MASK == 2 || j0 + KB > p.lk;         // uniform: interior tiles of masks 0/1 skip the compares
     if (need_mask) {
 #pragma unroll
       for (int kb = 0; kb < 2; ++kb)
@@ -149,7 +152,7 @@ __global__ __launch_bounds__(256) void attn_kernel(const AttnP p) {
         for (int r = 0; r < 16; ++r) {
           const int j = j0 + kb * 32 + hi * 16 + r;
           bool ok;
-          if (p.mask == 2) { const int cb = j / p.k_seq_stride; ok = (j - cb * p.k_seq_stride) < p.lk && cb == my_ctx; }
+          if (MASK == 2) { const int cb = j / p.k_seq_stride; ok = (j - cb * p.k_seq_stride) < p.lk && cb == my_ctx; }
           else ok = j < p.lk;
           if (!ok) s[kb][r] = -INFINITY;
         }
@@ -161,7 +164,7 @@ __global__ __launch_bounds__(256) void attn_kernel(const AttnP p) {
       for (int r = 0; r < 16; ++r) mx = fmaxf(mx, s[kb][r]);
     mx = fmaxf(mx, __shfl_xor(mx, 32));
     const float m_new = fmaxf(m_run, mx * p.scale_log2e);       // running max of the SCALED scores (finite: starts at -1e30)
-    const float alpha = exp2f(m_run - m_new);
+    const float alpha = fast_exp2(m_run - m_new);
     m_run = m_new;
     float psum = 0.f;
     uint4 pf[4];
@@ -171,7 +174,7 @@ __global__ __launch_bounds__(256) void attn_kernel(const AttnP p) {
       for (int h = 0; h < 2; ++h) {
         float e[8];
 #pragma unroll
-        for (int r = 0; r < 8; ++r) { e[r] = exp2f(fmaf(s[kb][h * 8 + r], p.scale_log2e, -m_new)); psum += e[r]; }
+        for (int r = 0; r < 8; ++r) { e[r] = fast_exp2(fmaf(s[kb][h * 8 + r], p.scale_log2e, -m_new)); psum += e[r]; }
         pf[kb * 2 + h] = pack8<Tag>(e);
       }
     l_run = l_run * alpha + psum;
@@ -209,16 +212,22 @@ __global__ __launch_bounds__(256) void attn_kernel(const AttnP p) {
   }
 }
 
-template <typename Tag, int D>
-void launch_attn(const AttnP& p, hipStream_t st) {
+template <typename Tag, int D, int MASK>
+void launch_attn_m(const AttnP& p, hipStream_t st) {
   constexpr size_t lds = 2 * (KB * D * 2 + D * KB * 2);
   static bool attr_done = false;
   if (!attr_done) {
-    (void)hipFuncSetAttribute((const void*)attn_kernel<Tag, D>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    (void)hipFuncSetAttribute((const void*)attn_kernel<Tag, D, MASK>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     attr_done = true;
   }
   const dim3 grid((p.lq + QB - 1) / QB, p.heads, p.nseq);
-  hipLaunchKernelGGL((attn_kernel<Tag, D>), grid, dim3(256), lds, st, p);
+  hipLaunchKernelGGL((attn_kernel<Tag, D, MASK>), grid, dim3(256), lds, st, p);
+}
+template <typename Tag, int D>
+void launch_attn(const AttnP& p, hipStream_t st) {
+  if (p.mask == 0) launch_attn_m<Tag, D, 0>(p, st);
+  else if (p.mask == 1) launch_attn_m<Tag, D, 1>(p, st);
+  else launch_attn_m<Tag, D, 2>(p, st);
 }
 
 // ---------------------------------------------------------------------------------------------

@@ -142,7 +142,7 @@ def attention(q, k, vt, out, *, nseq, lq, heads, head_dim, mask, lk, k_seq_strid
     if ev is not None:
         tag = "bf16_tag" if a.dtype == TT_BF16 else "f16_tag"
         keys = lk * (ctx_batches if mask == 2 else 1)
-        _prof_end(ev, f"attn_kernel<{tag},{head_dim}>", 4.0 * nseq * heads * lq * lk * head_dim,
+        _prof_end(ev, f"attn_kernel<{tag},{head_dim},{mask}>", 4.0 * nseq * heads * lq * lk * head_dim,
                   shape=("attn", nseq * heads, lq, lk, mask, 0))
     return out
 
