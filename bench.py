@@ -101,21 +101,21 @@ def kernel_profile(loop, args):
     return agg
 
 
-CPU_SAMPLE_FRAMES = 2
+CPU_THREADS = 32      # torch-CPU on the 256-thread host of the GPU box is pathological (measured with
+                      # tools/cpu_threads_probe.py: one UNet forward 4.3 s at 32 threads, 13 s at 128, 275 s at 256)
 
 
 def cpu_baseline(mode, res):
     """The oracle (CPU restatement of the reference's eager op sequence, fp32, no hoists) timed on this box's host
-    cores on a BOUNDED sample of the same workload: one ControlNet + one UNet forward of ONE CFG half (B=1) on
-    CPU_SAMPLE_FRAMES of the 14 frames at full latent resolution.  Every op on the path is batched over frames
-    (convs, spatial attention) or runs per pixel over frames (temporal layers), so cost is linear in B*F; a full
-    step = 2 CFG halves x 14 frames -> the sample time is scaled by 2*14/CPU_SAMPLE_FRAMES."""
+    cores on ONE full denoise step of the same workload (ControlNet + UNet on the CFG batch of 2 x 14 frames + CFG +
+    Euler), un-warmed, with the thread count that is fastest for eager PyTorch on this host.  No extrapolation."""
     from oracle import models as om
-    cores = os.cpu_count() or 1
-    torch.set_num_threads(cores)
+    from oracle.scheduler import EulerDiscreteScheduler as OSched
+    from this_and_that_vdm_amd.utils.synthetic import synthetic_inputs
+    threads = min(CPU_THREADS, os.cpu_count() or 1)
+    torch.set_num_threads(threads)
     torch.set_flush_denormal(True)
     h, w = LATENT[res]
-    f = CPU_SAMPLE_FRAMES
     pat = torch.randn(1 << 20, generator=torch.Generator().manual_seed(0)) * 0.02
 
     def build(ctor):            # meta construction + pattern fill: avoids a minutes-long RNG init of 2.2 B parameters
@@ -132,20 +132,24 @@ def cpu_baseline(mode, res):
     with torch.no_grad():
         unet = build(lambda: om.UNetSpatioTemporalConditionModel(num_attention_heads=(5, 10, 20, 20), num_frames=FRAMES))
         cn = build(lambda: om.ControlNetModel()) if mode == "vgl" else None
-        x = torch.randn(1, f, 8, h, w)
-        ehs = torch.randn(1, CTX_TOKENS, CTX_DIM)
-        ati = torch.tensor([[6.0, 200.0, 0.1]])
-        down = mid = None
+        inp = synthetic_inputs(2, FRAMES, h, w, CTX_TOKENS, CTX_DIM, seed=0)
+        sched = OSched()
+        sched.set_timesteps(STEPS_PER_REQUEST)
+        t = sched.timesteps[0]
         t0 = time.perf_counter()
+        x = torch.cat([sched.scale_model_input(torch.cat([inp["latents"]] * 2), t), inp["image_latents"]], dim=2)
+        down = mid = None
         if cn is not None:
-            down, mid = cn(x, 1.0, ehs, ati, controlnet_cond=torch.randn(f, 4, h, w))
-        unet(x, 1.0, ehs, ati, down_block_additional_residuals=down, mid_block_additional_residual=mid)
-        sample_s = time.perf_counter() - t0
-    step_s = sample_s * 2 * FRAMES / f
-    return {"value": 1.0 / step_s, "unit": "denoise-steps/s", "cores": cores, "kind": "port",
-            "sample": f"oracle fp32 eager (torch {torch.__version__}, {cores} threads): 1 {'ControlNet+' if cn is not None else ''}"
-                      f"UNet forward, B=1, {f} of {FRAMES} frames at {h}x{w} latents = {sample_s:.1f} s; "
-                      f"step = 2 CFG halves x {FRAMES} frames -> x{2 * FRAMES // f} = {step_s:.0f} s/step"}
+            down, mid = cn(x, t, inp["encoder_hidden_states"], inp["added_time_ids"],
+                           controlnet_cond=torch.cat([inp["gesture_latents"]] * 2))
+        eps = unet(x, t, inp["encoder_hidden_states"], inp["added_time_ids"], down_block_additional_residuals=down,
+                   mid_block_additional_residual=mid)
+        u, c = eps.chunk(2)
+        sched.step(u + inp["guidance_scale"] * (c - u), t, inp["latents"])
+        step_s = time.perf_counter() - t0
+    return {"value": 1.0 / step_s, "unit": "denoise-steps/s", "cores": threads, "kind": "port",
+            "sample": f"oracle fp32 eager (torch {torch.__version__}, {threads} of {os.cpu_count()} hardware threads): ONE full "
+                      f"{mode.upper()} denoise step, CFG batch 2 x {FRAMES} frames at {h}x{w} latents = {step_s:.1f} s"}
 
 
 def main():
@@ -198,9 +202,13 @@ def main():
         agg = kernel_profile(loop, args)
         tot_flops = sum(v[1] for v in agg.values())
         name, (cnt, fl, sec) = max(agg.items(), key=lambda kv: kv[1][2])
+        traffic = None               # HBM bytes per launch of that kernel from the committed rocprofv3 PMC passes
+        tfile = os.path.join(REPO, "profiles", "r1_hbm_traffic.json")
+        if os.path.exists(tfile):
+            traffic = json.load(open(tfile)).get(f"{a.mode}_{a.res}", {}).get(name)
         roofline = {"bound": "mfma", "kernel": name, "launches_per_step": cnt,
                     "achieved": fl / sec / 1e12, "peak": PEAK_TFLOPS, "unit": "TFLOP/s",
-                    "frac": fl / sec / 1e12 / PEAK_TFLOPS, "traffic": None,
+                    "frac": fl / sec / 1e12 / PEAK_TFLOPS, "traffic": traffic,
                     "algorithmic_gflop_per_launch": fl / cnt / 1e9, "avg_launch_us": sec / cnt * 1e6}
         extras["mfma_kernels"] = {k: {"launches": v[0], "tflop": v[1] / 1e12, "ms": v[2] * 1e3,
                                       "tflops": v[1] / v[2] / 1e12} for k, v in sorted(agg.items(), key=lambda kv: -kv[1][2])}

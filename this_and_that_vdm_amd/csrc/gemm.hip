@@ -557,6 +557,8 @@ constexpr TileCfg kCfgs[] = {
   {128, 160, 32, 3, 4, 1},   // 11: 54 KiB
   {128, 320, 32, 3, 4, 2},   // 12: 8 waves, wave tile 32x160, 84 KiB
   {256, 320, 32, 3, 4, 2},   // 13: 8 waves, wave tile 64x160, 108 KiB
+  {256, 256, 64, 2, 2, 4},   // 14: 8 waves, wave tile 128x64, 128 KiB, plain double buffer
+  {256, 128, 64, 2, 4, 2},   // 15: 8 waves, 96 KiB, plain double buffer
 };
 constexpr int kNumCfgs = sizeof(kCfgs) / sizeof(kCfgs[0]);
 
@@ -619,7 +621,9 @@ void launch(GemmP& p, int cfg, hipStream_t st) {
     case 10: launch_cfg<Tag, 128, 160, 64, 2, 4, 1>(p, st); break;
     case 11: launch_cfg<Tag, 128, 160, 32, 3, 4, 1>(p, st); break;
     case 12: launch_cfg<Tag, 128, 320, 32, 3, 4, 2>(p, st); break;
-    default: launch_cfg<Tag, 256, 320, 32, 3, 4, 2>(p, st); break;
+    case 13: launch_cfg<Tag, 256, 320, 32, 3, 4, 2>(p, st); break;
+    case 14: launch_cfg<Tag, 256, 256, 64, 2, 2, 4>(p, st); break;
+    default: launch_cfg<Tag, 256, 128, 64, 2, 4, 2>(p, st); break;
   }
 }
 
