@@ -5,7 +5,7 @@
 namespace {
 
 constexpr int GN_GROUPS = 32;
-constexpr int GN_ROWS_PER_CHUNK = 64;
+constexpr int GN_ROWS_PER_CHUNK = 128;
 
 // partial sums per (image, row-chunk, group): ws[((img*chunks + chunk)*32 + g)*2 + {0,1}] (double)
 template <typename Tag>
@@ -27,9 +27,25 @@ __global__ void gn_partial_kernel(const char* x0, int c0, const char* x1, int c1
     const int ch = myv * 8;
     const char* base; long ld; int coff;
     if (ch < c0) { base = x0; ld = c0; coff = ch; } else { base = x1; ld = c1; coff = ch - c0; }
-    for (int r = r0 + myr; r < r1; r += rpb) {
+    // 4 independent 16-byte loads in flight per thread (the kernel is a pure HBM stream)
+    const char* pbase = base + (((long)img * hw) * ld + coff) * 2;
+    const long rstride = ld * 2;
+    int r = r0 + myr;
+    for (; r + 3 * rpb < r1; r += 4 * rpb) {
+      uint4 v[4];
+#pragma unroll
+      for (int k = 0; k < 4; ++k) v[k] = *(const uint4*)(pbase + (long)(r + k * rpb) * rstride);
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        float f[8];
+        unpack8<Tag>(v[k], f);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) { s[e] += f[e]; q[e] = fmaf(f[e], f[e], q[e]); }
+      }
+    }
+    for (; r < r1; r += rpb) {
       float f[8];
-      unpack8<Tag>(*(const uint4*)(base + (((long)img * hw + r) * ld + coff) * 2), f);
+      unpack8<Tag>(*(const uint4*)(pbase + (long)r * rstride), f);
 #pragma unroll
       for (int e = 0; e < 8; ++e) { s[e] += f[e]; q[e] = fmaf(f[e], f[e], q[e]); }
     }

@@ -38,9 +38,10 @@ _WS = {}
 def _workspace(nbytes: int, device) -> torch.Tensor:
     """Persistent split-K scratch per device (grown on demand; sized during warm-up, so a captured graph keeps a
     stable pointer).  Launches on one stream are ordered, so every GEMM can share it."""
-    buf = _WS.get(device)
+    key = (device, torch.cuda.current_stream().cuda_stream)      # per stream: concurrent branches must not share slabs
+    buf = _WS.get(key)
     if buf is None or buf.numel() < nbytes:
-        buf = _WS[device] = torch.empty(max(nbytes, 64 << 20), dtype=torch.uint8, device=device)
+        buf = _WS[key] = torch.empty(max(nbytes, 64 << 20), dtype=torch.uint8, device=device)
     return buf
 
 

@@ -93,17 +93,36 @@ class DenoiseLoop:
         x_tok = ops.prep_model_input(self.latents, self.image_latents, self.cond, self.cur, 0, g.batch, g.frames, g.h, g.w,
                                      cpad, self.dtype)
         t = self.cur[2:3]
-        emb_u = self.unet._embed(t, self.added_time_ids, g.batch, x_tok.device)
-        ctx_u = self.unet._step_context(emb_u, self.ctx_unet)
         x_unet = x_tok if cpad == self.unet._cin_pad else x_tok[:, :self.unet._cin_pad]
-        x, gm, skips = self.unet.encode_tokens(x_unet, g, ctx_u)
-        if self.controlnet is not None:
-            emb_c = self.controlnet._embed(t, self.added_time_ids, g.batch, x_tok.device)
-            down, (x, _) = self.controlnet.forward_tokens(x_tok, g, emb_c, self.ctx_cn, self.cn_scales,
-                                                          add_to=([s for s, _ in skips], x))
-            skips = down
+        if self.controlnet is None:
+            ctx_u = self.unet._step_context(self.unet._embed(t, self.added_time_ids, g.batch, x_tok.device), self.ctx_unet)
+            x, gm, skips = self.unet.encode_tokens(x_unet, g, ctx_u)
+        else:
+            # GestureNet encoder+mid and UNet encoder+mid are independent until the zero-convs: run them as two
+            # branches (fork/join with events; captured as parallel graph branches) so the latency-bound small kernels
+            # and the tails of one fill the idle CUs of the other.
+            main = torch.cuda.current_stream()
+            side = self._side_stream()
+            fork = torch.cuda.Event()
+            fork.record(main)
+            side.wait_event(fork)
+            with torch.cuda.stream(side):
+                ctx_c = self.controlnet._step_context(self.controlnet._embed(t, self.added_time_ids, g.batch, x_tok.device),
+                                                      self.ctx_cn)
+                cn_skips, cn_mid, _ = self.controlnet.encode_tokens(x_tok, g, ctx_c)
+                join = torch.cuda.Event()
+                join.record(side)
+            ctx_u = self.unet._step_context(self.unet._embed(t, self.added_time_ids, g.batch, x_tok.device), self.ctx_unet)
+            x, gm, skips = self.unet.encode_tokens(x_unet, g, ctx_u)
+            main.wait_event(join)
+            skips, (x, _) = self.controlnet.zero_convs(cn_skips, cn_mid, gm, self.cn_scales, add_to=([s for s, _ in skips], x))
         eps = self.unet.decode_tokens(x, gm, skips, ctx_u)
         ops.cfg_euler_step(eps, self.latents, self.guidance, self.cur, 0, g.batch, g.frames, g.h, g.w)
+
+    def _side_stream(self):
+        if getattr(self, "_side", None) is None:
+            self._side = torch.cuda.Stream()
+        return self._side
 
     def step(self):
         """Advance the latents by one Euler step (asynchronous; call torch.cuda.synchronize() to wait)."""

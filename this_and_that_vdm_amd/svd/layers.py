@@ -54,7 +54,8 @@ class StepContext:
         """Scratch for the transposed V projection of self-attention.  Persistent per shape: padding columns
         (sequence length not a multiple of 8) are zeroed once and never written, and launches on one stream
         are ordered, so layers can share it."""
-        key = (like.device, like.dtype, c, cols)
+        # one scratch per (stream, shape): the fused loop runs GestureNet and UNet encoders on two streams
+        key = (like.device, like.dtype, c, cols, torch.cuda.current_stream().cuda_stream)
         buf = StepContext._VT_CACHE.get(key)
         if buf is None:
             buf = StepContext._VT_CACHE[key] = torch.zeros((c, cols), dtype=like.dtype, device=like.device)

@@ -122,20 +122,28 @@ class ControlNetModel(DenoiserBase, ConfigMixin):
         self._zero_mid = (pack_conv1x1(self.controlnet_mid_block.weight.detach().to(dtype)), _f32(self.controlnet_mid_block.bias))
 
     # ---- forward
-    def forward_tokens(self, x_tok, g: Geom, emb, context, scales: List[float], add_to=None):
-        """x_tok [M, cin_pad] (latent | image-latent | gesture-latent channels) -> 12 down residuals + mid residual.
-        If ``add_to`` = (unet_skips, unet_mid) the zero-conv epilogue adds the UNet tensors (fused residual add)."""
-        ctx = self._step_context(emb, context)
+    def encode_tokens(self, x_tok, g: Geom, ctx):
+        """conv_in_concat + 4 down blocks + mid block -> (12 skips [(tok, geom)], mid tokens, mid geom)."""
         x = ops.gemm(x_tok, self._w_in, mode=1, conv=(g.n, g.h, g.w, g.h, g.w, 1, 0), bias=self._b_in)
         x, gm, skips = self._encode(x, g, ctx)
-        x = self.mid_block(x, gm, ctx)
+        return skips, self.mid_block(x, gm, ctx), gm
+
+    def zero_convs(self, skips, mid, gm: Geom, scales: List[float], add_to=None):
+        """12 + 1 zero-initialised 1x1 convs (:614-622) with the conditioning scale as acc_scale; with ``add_to`` =
+        (unet_skips, unet_mid) the UNet tensors are added in the epilogue (fused `skip += residual`)."""
         down = []
         for i, ((s, sg), (wz, bz)) in enumerate(zip(skips, self._zero)):
             res = add_to[0][i] if add_to is not None else None
             down.append((ops.gemm(s, wz, bias=bz, acc_scale=scales[i], residual=res), sg))
-        mid = ops.gemm(x, self._zero_mid[0], bias=self._zero_mid[1], acc_scale=scales[-1],
-                       residual=add_to[1] if add_to is not None else None)
-        return down, (mid, gm)
+        mid_out = ops.gemm(mid, self._zero_mid[0], bias=self._zero_mid[1], acc_scale=scales[-1],
+                           residual=add_to[1] if add_to is not None else None)
+        return down, (mid_out, gm)
+
+    def forward_tokens(self, x_tok, g: Geom, emb, context, scales: List[float], add_to=None):
+        """x_tok [M, cin_pad] (latent | image-latent | gesture-latent channels) -> 12 down residuals + mid residual."""
+        ctx = self._step_context(emb, context)
+        skips, mid, gm = self.encode_tokens(x_tok, g, ctx)
+        return self.zero_convs(skips, mid, gm, scales, add_to)
 
     def _scales(self, conditioning_scale: float, guess_mode: bool, n_down: int) -> List[float]:
         if guess_mode:                                                   # :626-630 logspace(-1, 0, 13) * scale
