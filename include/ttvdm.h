@@ -109,6 +109,7 @@ typedef struct TtAttnArgs {
   int32_t k_seq_stride, v_seq_stride;  /* rows of k / columns of vt per sequence (mask 0) or per context (1,2) */
   int32_t frames, ctx_batches;         /* masks 1,2 */
   int32_t dtype;
+  int32_t batch0;                      /* masks 1,2: batch index of sequence 0 (a launch may cover a sub-range of the batch) */
 } TtAttnArgs;
 int tt_attention(const TtAttnArgs* args, tt_stream_t stream);
 

@@ -43,6 +43,10 @@ def test_fused_loop_matches_oracle_loop(with_cn):
         outs[graph] = loop.run().clone()
         torch.cuda.synchronize()
     assert torch.equal(outs[True], outs[False]), "graph replay must equal eager launches"
+    # CFG halves as separate concurrent branches: same arithmetic per element, must agree exactly as well
+    split = DenoiseLoop(p_unet, p_cn, use_graph=True, split_cfg=True).begin(**kw).run().clone()
+    torch.cuda.synchronize()
+    assert torch.equal(split, outs[True]), "split-CFG branches must reproduce the joint launch"
     s = err_stats(outs[True], ref)
     print("fused loop vs oracle loop:", s)
     assert s["rel_l2"] <= 1e-2 and s["cos"] >= 0.9999, s

@@ -36,7 +36,7 @@ class TtAttnArgs(C.Structure):
         ("vt", C.c_void_p), ("ldvt", C.c_int64), ("out", C.c_void_p), ("ldo", C.c_int64),
         ("nseq", C.c_int32), ("lq", C.c_int32), ("heads", C.c_int32), ("head_dim", C.c_int32),
         ("mask", C.c_int32), ("lk", C.c_int32), ("k_seq_stride", C.c_int32), ("v_seq_stride", C.c_int32),
-        ("frames", C.c_int32), ("ctx_batches", C.c_int32), ("dtype", C.c_int32),
+        ("frames", C.c_int32), ("ctx_batches", C.c_int32), ("dtype", C.c_int32), ("batch0", C.c_int32),
     ]
 
 

@@ -19,7 +19,7 @@ struct AttnP {
   const char* vt; long ldvt;
   char* out; long ldo;
   int nseq, lq, heads;
-  int mask, lk, k_seq_stride, v_seq_stride, frames, ctx_batches;
+  int mask, lk, k_seq_stride, v_seq_stride, frames, ctx_batches, batch0;
   int k_rows_total;     // rows of k that exist
   long vt_cols_total;   // columns of vt that exist
   unsigned k_bytes, vt_bytes;   // extents for the buffer descriptors
@@ -52,7 +52,7 @@ __global__ __launch_bounds__(256) void attn_kernel(const AttnP p) {
   // ---- which keys does this sequence see
   int kbase, vbase, ntiles;
   if (MASK == 0) { kbase = seq * p.k_seq_stride; vbase = seq * p.v_seq_stride; ntiles = (p.lk + KB - 1) / KB; }
-  else if (MASK == 1) { const int b = seq / p.frames; kbase = b * p.k_seq_stride; vbase = b * p.v_seq_stride; ntiles = (p.lk + KB - 1) / KB; }
+  else if (MASK == 1) { const int b = p.batch0 + seq / p.frames; kbase = b * p.k_seq_stride; vbase = b * p.v_seq_stride; ntiles = (p.lk + KB - 1) / KB; }
   else { kbase = 0; vbase = 0; ntiles = (p.ctx_batches * p.k_seq_stride + KB - 1) / KB; }
 
   // ---- Q^T fragments straight from global: lane (query l31) holds d = ds*16 + hi*8 .. +8
@@ -66,7 +66,7 @@ __global__ __launch_bounds__(256) void attn_kernel(const AttnP p) {
   }
   // temporal-cross pairing (reference quirk Q3): the context this query may look at
   int my_ctx = 0;
-  if (MASK == 2) my_ctx = (int)((((long)(seq / p.frames)) * p.lq + (qok ? qrow : 0)) % p.ctx_batches);
+  if (MASK == 2) my_ctx = (int)((((long)(p.batch0 + seq / p.frames)) * p.lq + (qok ? qrow : 0)) % p.ctx_batches);
 
   // staging by buffer_load ... lds: per-lane 32-bit byte offsets computed once, the tile position is a scalar offset,
   // out-of-range rows/columns land beyond num_records and read as zeros (same scheme as gemm.hip).
@@ -350,6 +350,7 @@ extern "C" int tt_attention(const TtAttnArgs* a, tt_stream_t stream) {
   if ((a->ldq & 7) || (a->ldk & 7) || (a->ldvt & 7) || (a->ldo & 3) || (a->v_seq_stride & 7))
     TT_FAIL(TT_EINVAL, "tt_attention: strides must keep 16-byte chunks aligned");
   if (a->mask != 0 && (a->frames <= 0 || a->ctx_batches <= 0 || a->nseq % a->frames)) TT_FAIL(TT_EINVAL, "tt_attention: frames/ctx");
+  if (a->mask != 0 && (a->batch0 < 0 || a->batch0 + a->nseq / a->frames > a->ctx_batches)) TT_FAIL(TT_EINVAL, "tt_attention: batch0 + batches exceeds ctx_batches");
   if (a->lk > a->k_seq_stride || a->lk > a->v_seq_stride) TT_FAIL(TT_EINVAL, "tt_attention: lk exceeds sequence stride");
   if (a->mask == 2 && a->k_seq_stride != a->v_seq_stride) TT_FAIL(TT_EINVAL, "tt_attention: mask 2 needs equal k/v context strides");
   if (a->dtype != TT_BF16 && a->dtype != TT_F16) TT_FAIL(TT_EINVAL, "tt_attention: bad dtype");
@@ -357,7 +358,7 @@ extern "C" int tt_attention(const TtAttnArgs* a, tt_stream_t stream) {
   p.q = (const char*)a->q; p.ldq = a->ldq; p.k = (const char*)a->k; p.ldk = a->ldk;
   p.vt = (const char*)a->vt; p.ldvt = a->ldvt; p.out = (char*)a->out; p.ldo = a->ldo;
   p.nseq = a->nseq; p.lq = a->lq; p.heads = a->heads; p.mask = a->mask; p.lk = a->lk;
-  p.k_seq_stride = a->k_seq_stride; p.v_seq_stride = a->v_seq_stride; p.frames = a->frames; p.ctx_batches = a->ctx_batches;
+  p.k_seq_stride = a->k_seq_stride; p.v_seq_stride = a->v_seq_stride; p.frames = a->frames; p.ctx_batches = a->ctx_batches; p.batch0 = a->batch0;
   const int nctx = a->mask == 0 ? a->nseq : a->ctx_batches;
   p.k_rows_total = nctx * a->k_seq_stride;
   p.vt_cols_total = (long)nctx * a->v_seq_stride;

@@ -128,7 +128,8 @@ def gemm(a0: torch.Tensor, w: torch.Tensor, *, a1: Optional[torch.Tensor] = None
     return out
 
 
-def attention(q, k, vt, out, *, nseq, lq, heads, head_dim, mask, lk, k_seq_stride, v_seq_stride, frames=1, ctx_batches=1):
+def attention(q, k, vt, out, *, nseq, lq, heads, head_dim, mask, lk, k_seq_stride, v_seq_stride, frames=1, ctx_batches=1,
+              batch0=0):
     lib = _lib.load()
     a = TtAttnArgs()
     a.q, a.ldq = _p(q), q.stride(0)
@@ -137,7 +138,7 @@ def attention(q, k, vt, out, *, nseq, lq, heads, head_dim, mask, lk, k_seq_strid
     a.out, a.ldo = _p(out), out.stride(0)
     a.nseq, a.lq, a.heads, a.head_dim = nseq, lq, heads, head_dim
     a.mask, a.lk, a.k_seq_stride, a.v_seq_stride = mask, lk, k_seq_stride, v_seq_stride
-    a.frames, a.ctx_batches, a.dtype = frames, ctx_batches, _code(q.dtype)
+    a.frames, a.ctx_batches, a.dtype, a.batch0 = frames, ctx_batches, _code(q.dtype), batch0
     ev = _prof_begin()
     check(lib.tt_attention(C.byref(a), _stream()), "tt_attention")
     if ev is not None:

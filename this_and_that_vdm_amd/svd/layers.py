@@ -23,10 +23,12 @@ from ..packing import pack_conv1x1, pack_conv3x3, pack_geglu, pack_tconv3
 
 @dataclass
 class Geom:
-    batch: int       # B (CFG-expanded)
+    batch: int       # B (CFG-expanded) covered by this launch
     frames: int      # F
     h: int
     w: int
+    batch0: int = 0          # index of its first batch element inside the request ...
+    batch_total: int = 0     # ... and the request's full batch (0 = same as `batch`): the fused loop runs CFG halves apart
 
     @property
     def n(self):
@@ -39,6 +41,14 @@ class Geom:
     @property
     def m(self):
         return self.n * self.hw
+
+    @property
+    def ctx_batches(self):
+        return self.batch_total or self.batch
+
+    def film(self, film: torch.Tensor, off: int, c: int) -> torch.Tensor:
+        """FiLM rows of this launch's batch elements, columns [off, off+c)."""
+        return film[self.batch0:self.batch0 + self.batch, off:off + c]
 
 
 class StepContext:
@@ -165,7 +175,7 @@ class ResnetBlock2D(_Packable):
         off, c = self.film
         conv = (g.n, g.h, g.w, g.h, g.w, 1, 0)
         a = _gn(x0, x1, g, 1, self.g1, self.be1, self.eps, True)
-        hmid = ops.gemm(a, self.w1, mode=1, conv=conv, bias=self.b1, rowvec=ctx.film[:, off:off + c],
+        hmid = ops.gemm(a, self.w1, mode=1, conv=conv, bias=self.b1, rowvec=g.film(ctx.film, off, c),
                         rowvec_rows=g.frames * g.hw)
         a = _gn(hmid, None, g, 1, self.g2, self.be2, self.eps, True)
         if self.conv_shortcut is not None:
@@ -203,7 +213,7 @@ class TemporalResnetBlock(_Packable):
     def forward(self, s, g: Geom, ctx: StepContext, alpha: float):
         off, c = self.film
         a = _gn(s, None, g, g.frames, self.g1, self.be1, self.eps, True)
-        t = ops.gemm(a, self.w1, mode=2, tconv=(g.frames, g.hw), bias=self.b1, rowvec=ctx.film[:, off:off + c],
+        t = ops.gemm(a, self.w1, mode=2, tconv=(g.frames, g.hw), bias=self.b1, rowvec=g.film(ctx.film, off, c),
                      rowvec_rows=g.frames * g.hw)
         a = _gn(t, None, g, g.frames, self.g2, self.be2, self.eps, True)
         # x_temporal = s + conv2(...);  out = alpha*s + (1-alpha)*x_temporal
@@ -258,7 +268,7 @@ class Downsample2D(_Packable):
     def forward(self, x, g: Geom):
         ho, wo = (g.h + 2 - 3) // 2 + 1, (g.w + 2 - 3) // 2 + 1
         out = ops.gemm(x, self.w, mode=1, conv=(g.n, g.h, g.w, ho, wo, 2, 0), bias=self.b)
-        return out, Geom(g.batch, g.frames, ho, wo)
+        return out, Geom(g.batch, g.frames, ho, wo, g.batch0, g.batch_total)
 
 
 class Upsample2D(_Packable):
@@ -275,7 +285,7 @@ class Upsample2D(_Packable):
     def forward(self, x, g: Geom):
         # nearest x2 is an index map inside the conv gather: never materialised
         out = ops.gemm(x, self.w, mode=1, conv=(g.n, g.h, g.w, 2 * g.h, 2 * g.w, 1, 1), bias=self.b)
-        return out, Geom(g.batch, g.frames, 2 * g.h, 2 * g.w)
+        return out, Geom(g.batch, g.frames, 2 * g.h, 2 * g.w, g.batch0, g.batch_total)
 
 
 # --------------------------------------------------------------------------- attention / feed-forward
@@ -337,7 +347,7 @@ def _cross_attention(x_norm, attn: Attention, wq, kv, g: Geom, ctx: StepContext,
     out = torch.empty((g.m, c), dtype=x_norm.dtype, device=x_norm.device)
     return ops.attention(q, ctx.k_all[:, off:off + c], ctx.vt_all[off:off + c], out, nseq=g.n, lq=g.hw, heads=attn.heads,
                          head_dim=attn.dim_head, mask=2 if temporal else 1, lk=ctx.s_ctx, k_seq_stride=ctx.s_pad,
-                         v_seq_stride=ctx.s_pad, frames=g.frames, ctx_batches=g.batch)
+                         v_seq_stride=ctx.s_pad, frames=g.frames, ctx_batches=g.ctx_batches, batch0=g.batch0)
 
 
 class BasicTransformerBlock(_Packable):

@@ -117,13 +117,14 @@ class UNetSpatioTemporalConditionModel(DenoiserBase, ConfigMixin):
         x, gm, skips = self._encode(x, g, ctx)
         return self.mid_block(x, gm, ctx), gm, skips
 
-    def decode_tokens(self, x, gm: Geom, skips, ctx):
-        """4 up blocks + GN/SiLU/conv_out -> eps fp32 [M, out_channels]."""
+    def decode_tokens(self, x, gm: Geom, skips, ctx, eps_out=None):
+        """4 up blocks + GN/SiLU/conv_out -> eps fp32 [M, out_channels] (written into ``eps_out`` if given)."""
         skips = list(skips)
         for blk in self.up_blocks:
             x, gm = blk(x, skips, gm, ctx)
         a = _gn(x, None, gm, 1, self._gn_out[0], self._gn_out[1], 1e-5, True)
-        return ops.gemm(a, self._w_out, mode=1, conv=(gm.n, gm.h, gm.w, gm.h, gm.w, 1, 0), bias=self._b_out, out_f32=True)
+        return ops.gemm(a, self._w_out, mode=1, conv=(gm.n, gm.h, gm.w, gm.h, gm.w, 1, 0), bias=self._b_out, out_f32=True,
+                        out=eps_out)
 
     def forward_tokens(self, x_tok, g: Geom, emb, context, down_res_tok=None, mid_res_tok=None):
         """Token-level core: x_tok [M, cin_pad] -> eps fp32 [M, out_channels].  The reference adds the ControlNet
