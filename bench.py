@@ -85,6 +85,7 @@ def kernel_profile(loop, args):
     from this_and_that_vdm_amd import ops
     loop.begin(**args)
     loop.use_graph = False
+    loop.overlap_branches = False                   # one stream: each kernel is timed alone on the chip
     loop.step()                                     # eager warm-up
     torch.cuda.synchronize()
     ops.PROFILE = []
@@ -92,6 +93,7 @@ def kernel_profile(loop, args):
     torch.cuda.synchronize()
     rec, ops.PROFILE = ops.PROFILE, None
     loop.use_graph = True
+    loop.overlap_branches = True
     agg = {}
     for name, flops, e0, e1, _shape in rec:
         a = agg.setdefault(name, [0, 0.0, 0.0])

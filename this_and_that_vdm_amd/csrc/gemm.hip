@@ -108,8 +108,20 @@ template <int G> __device__ __forceinline__ void wait_tiles(int tiles) {
   else wait_vmcnt<3 * G>();
 }
 
+// LDS bytes of one workgroup and the waves per SIMD the register allocator must leave room for: as many workgroups per
+// CU as the 160 KiB of LDS admit (at most 2 -- more did not pay), i.e. blocks * waves / 4 SIMDs.  Declaring it keeps e.g.
+// the 256x128 8-wave kernel at <= 128 VGPRs (130 would halve its occupancy).
+constexpr int gemm_lds_bytes(int BM, int BN, int BK, int NST, int NT) {
+  return NST * (((BM * (BK / 8) + NT - 1) / NT) + ((BN * (BK / 8) + NT - 1) / NT)) * NT * 16;
+}
+constexpr int gemm_min_waves(int BM, int BN, int BK, int NST, int NT) {
+  const int blocks = (160 * 1024) / gemm_lds_bytes(BM, BN, BK, NST, NT) >= 2 ? 2 : 1;
+  return blocks * (NT / 64) / 4;
+}
+
 template <typename Tag, int BM, int BN, int BK, int NST, int WGM, int WGN, int MODE>
-__global__ __launch_bounds__(64 * WGM * WGN) void gemm_kernel(const GemmP p) {
+__global__ __launch_bounds__(64 * WGM * WGN, gemm_min_waves(BM, BN, BK, NST, 64 * WGM * WGN))
+void gemm_kernel(const GemmP p) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   constexpr int NT = 64 * WGM * WGN;                   // threads
   constexpr int CPR = BK / 8;                          // 16-byte chunks per tile row
@@ -378,9 +390,10 @@ __global__ __launch_bounds__(64 * WGM * WGN) void gemm_kernel(const GemmP p) {
         }
     }
     __syncthreads();                                   // all waves are done with the operand ring
-    constexpr int ROWE = 64 * 4 + 16;                  // strip row: 64 fp32 + pad (bank spread)
-    char* ebuf = smem + wid * (32 * ROWE);
-    static_assert(WGM * WGN * 32 * ROWE <= NST * STAGE, "epilogue strip does not fit the ring");
+    // strip = 32 rows x 256 bytes per wave, 16-byte quads XOR-swizzled by the row (no padding: 8 KiB per wave)
+    auto strip_off = [](int row, int quad, int nq) { return row * 256 + ((quad ^ (row & (nq - 1))) << 4); };
+    char* ebuf = smem + wid * 8192;
+    static_assert(WGM * WGN * 8192 <= NST * STAGE, "epilogue strips do not fit the ring");
 #pragma unroll
     for (int i = 0; i < FM; ++i) {
       const int mb = m0 + wr * WTM + i * 32;
@@ -394,7 +407,7 @@ __global__ __launch_bounds__(64 * WGM * WGN) void gemm_kernel(const GemmP p) {
             if (jc + jj < FN) {
 #pragma unroll
               for (int g = 0; g < 4; ++g)
-                *(float4*)(ebuf + l31 * ROWE + (jj * 32 + 8 * g + 4 * hi) * 4) =
+                *(float4*)(ebuf + strip_off(l31, jj * 8 + 2 * g + hi, nfr * 8)) =
                     make_float4(acc[i][jc + jj][g * 4], acc[i][jc + jj][g * 4 + 1], acc[i][jc + jj][g * 4 + 2], acc[i][jc + jj][g * 4 + 3]);
             }
           }
@@ -406,7 +419,7 @@ __global__ __launch_bounds__(64 * WGM * WGN) void gemm_kernel(const GemmP p) {
           for (int pass = 0; pass < 32 * QMAX / 64; ++pass) {
             if (pass * rows_per_pass < 32) {
               const int r = pass * rows_per_pass + rr;
-              const float4 t = *(const float4*)(ebuf + r * ROWE + qq * 16);
+              const float4 t = *(const float4*)(ebuf + strip_off(r, qq, q_per_row));
               const int gm = mb + r;
               if (gm < p.m && gn < p.n) {
                 float v[4] = {t.x, t.y, t.z, t.w};
@@ -437,7 +450,7 @@ __global__ __launch_bounds__(64 * WGM * WGN) void gemm_kernel(const GemmP p) {
                   if (p.bias && gnp < p.n) { a += p.bias[gnp + e]; g2 += p.bias[gnp + 8 + e]; }
                   v[e] = a * gelu_erf_f(g2);
                 }
-                *(float4*)(ebuf + l31 * ROWE + (jj * 16 + tt * 8 + 4 * hi) * 4) = make_float4(v[0], v[1], v[2], v[3]);
+                *(float4*)(ebuf + strip_off(l31, jj * 4 + tt * 2 + hi, nfr * 4)) = make_float4(v[0], v[1], v[2], v[3]);
               }
             }
           }
@@ -449,7 +462,7 @@ __global__ __launch_bounds__(64 * WGM * WGN) void gemm_kernel(const GemmP p) {
           for (int pass = 0; pass < 4; ++pass) {
             if (pass * rows_per_pass < 32) {
               const int r = pass * rows_per_pass + rr;
-              const float4 t = *(const float4*)(ebuf + r * ROWE + qq * 16);
+              const float4 t = *(const float4*)(ebuf + strip_off(r, qq, q_per_row));
               const int gm = mb + r;
               if (gm < p.m && oc * 2 < p.n)
                 *(uint2*)(p.out + ((long)gm * p.ldo + oc) * 2) = make_uint2(pack2<Tag>(t.x, t.y), pack2<Tag>(t.z, t.w));
@@ -559,6 +572,12 @@ constexpr TileCfg kCfgs[] = {
   {256, 320, 32, 3, 4, 2},   // 13: 8 waves, wave tile 64x160, 108 KiB
   {256, 256, 64, 2, 2, 4},   // 14: 8 waves, wave tile 128x64, 128 KiB, plain double buffer
   {256, 128, 64, 2, 4, 2},   // 15: 8 waves, 96 KiB, plain double buffer
+  {128, 128, 64, 4, 2, 2},   // 16: 128 KiB, 1 block/CU, prefetch distance 3
+  {128, 128, 32, 5, 2, 2},   // 17: 80 KiB, 2 blocks/CU, prefetch distance 4 (x32)
+  {128, 128, 64, 2, 4, 2},   // 18: 8 waves (wave tile 32x64), 64 KiB -> 16 waves/CU
+  {128, 128, 32, 2, 2, 2},   // 19: 4 waves, 32 KiB
+  {256, 160, 32, 3, 8, 1},   // 20: N = 320/960, 8 waves (wave tile 32x160), 78 KiB -> 2 blocks/CU
+  {256, 128, 32, 4, 4, 2},   // 21: like 3 with one more stage (96 KiB, 1 block/CU)
 };
 constexpr int kNumCfgs = sizeof(kCfgs) / sizeof(kCfgs[0]);
 
@@ -590,7 +609,7 @@ Plan make_plan(int m, int n, long ktot, bool allow_split) {
   else if (n % 160 == 0 && n % 128 != 0 && n <= 960 && m >= 2048) pl.cfg = 10;
   else if (m >= 8192 && n >= 1024) pl.cfg = 3;
   else if (m < 2048 && n >= 2560 && n % 160 == 0) pl.cfg = 10;
-  else if (b128 >= 384) pl.cfg = 0;
+  else if (b128 >= 384) pl.cfg = 18;                 // 128x128 with 8 waves (32x64 wave tiles): 16 waves per CU
   else if (b12864 >= 384) pl.cfg = 1;
   else pl.cfg = 2;
   const int fs = forced_split();
@@ -600,7 +619,7 @@ Plan make_plan(int m, int n, long ktot, bool allow_split) {
     long s = (512 + b128 - 1) / b128;
     if (s > kt / 8) s = kt / 8;
     if (s > 16) s = 16;
-    if (s >= 2) { pl.cfg = 0; pl.splitk = (int)s; }
+    if (s >= 2) { pl.cfg = 18; pl.splitk = (int)s; }
   }
   return pl;
 }
@@ -623,7 +642,13 @@ void launch(GemmP& p, int cfg, hipStream_t st) {
     case 12: launch_cfg<Tag, 128, 320, 32, 3, 4, 2>(p, st); break;
     case 13: launch_cfg<Tag, 256, 320, 32, 3, 4, 2>(p, st); break;
     case 14: launch_cfg<Tag, 256, 256, 64, 2, 2, 4>(p, st); break;
-    default: launch_cfg<Tag, 256, 128, 64, 2, 4, 2>(p, st); break;
+    case 15: launch_cfg<Tag, 256, 128, 64, 2, 4, 2>(p, st); break;
+    case 16: launch_cfg<Tag, 128, 128, 64, 4, 2, 2>(p, st); break;
+    case 17: launch_cfg<Tag, 128, 128, 32, 5, 2, 2>(p, st); break;
+    case 18: launch_cfg<Tag, 128, 128, 64, 2, 4, 2>(p, st); break;
+    case 19: launch_cfg<Tag, 128, 128, 32, 2, 2, 2>(p, st); break;
+    case 20: launch_cfg<Tag, 256, 160, 32, 3, 8, 1>(p, st); break;
+    default: launch_cfg<Tag, 256, 128, 32, 4, 4, 2>(p, st); break;
   }
 }
 

@@ -26,6 +26,7 @@ class DenoiseLoop:
         # run the uncond / cond halves as separate concurrent branches too (measured SLOWER on MI355X at 256x448:
         # 47.7 vs 44.4 ms/step -- half-size GEMMs lose more than the overlap wins; kept as an option and tested)
         self.split_cfg = split_cfg
+        self.overlap_branches = True        # False: same launches, one stream (used when timing kernels one by one)
         self._streams = {}
         self._graph = None
         self._key = None
@@ -142,6 +143,8 @@ class DenoiseLoop:
         ops.cfg_euler_step(eps, self.latents, self.guidance, self.cur, 0, g.batch, g.frames, g.h, g.w)
 
     def _stream(self, name):
+        if not self.overlap_branches:
+            return torch.cuda.current_stream()
         st = self._streams.get(name)
         if st is None:
             st = self._streams[name] = torch.cuda.Stream()

@@ -9,5 +9,6 @@ dev = torch.device("cuda", 0)
 unet, cn, _ = bench.build_models(mode, torch.bfloat16, dev, 0, 1)
 loop, args = bench.make_loop(unet, cn, res, dev, 0)
 loop.use_graph = False
+loop.overlap_branches = False
 loop.step(); loop.step()
 torch.cuda.synchronize()

@@ -12,6 +12,7 @@ def main():
     unet, cn, _ = bench.build_models(mode, torch.bfloat16, dev, 0, 1)
     loop, args = bench.make_loop(unet, cn, res, dev, 0)
     loop.use_graph = False
+    loop.overlap_branches = False
     loop.step(); torch.cuda.synchronize()
     ops.PROFILE = []
     loop.step(); torch.cuda.synchronize()
