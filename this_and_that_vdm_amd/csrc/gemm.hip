@@ -37,10 +37,44 @@ struct GemmP {
   int nk0, nk1, taps, kt_total;     // derived: K steps per source, taps, total K steps
   int tiles_m, tiles_n;
   unsigned a0_bytes, a1_bytes, w_bytes;   // extents for the buffer descriptors (< 2 GiB each)
+  unsigned out_bytes, res_bytes, blend_bytes, bias_bytes, rowvec_bytes, ws_bytes;   // epilogue descriptors (0 = absent)
   int splitk;                       // > 1: block (tile, s) reduces K slice s and writes an fp32 slab to ws
   float* ws;                        // [splitk][m][n] fp32 partial sums
 };
 
+
+// ---- optional per-block timeline (make timeline): thread 0 of every block stamps the 100 MHz wall clock
+#ifdef TT_GEMM_TIMELINE
+__device__ long long g_tl[8 * 8192];
+#define TL(i) do { if (threadIdx.x == 0 && blockIdx.x < 8192) g_tl[blockIdx.x * 8 + (i)] = wall_clock64(); } while (0)
+#else
+#define TL(i) do { } while (0)
+#endif
+
+// ---- branch-free global access for the epilogue: 128-bit buffer descriptors with hardware bounds checking.  An
+// offset of kInv (>= num_records) makes a load return 0 and drops a store, so ragged rows/columns and absent operands
+// (null base, 0 records) need no exec-masked branch -- with branches hipcc serialises every pass behind
+// `s_waitcnt vmcnt(0)` and the epilogue of one tile costs 4-8 us; straight-line it is ~1 us.
+constexpr int kInv = (int)0x80000000;
+typedef unsigned u32x2_t __attribute__((ext_vector_type(2)));
+typedef unsigned u32x4_t __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t make_rsrc(const void* ptr, unsigned bytes) {
+  return __builtin_amdgcn_make_buffer_rsrc((void*)ptr, 0, (int)bytes, 0x00020000);
+}
+__device__ __forceinline__ uint2 ld64(__amdgpu_buffer_rsrc_t r, int off) {
+  const u32x2_t v = __builtin_amdgcn_raw_buffer_load_b64(r, off, 0, 0);
+  return make_uint2(v.x, v.y);
+}
+__device__ __forceinline__ float4 ld128f(__amdgpu_buffer_rsrc_t r, int off) {
+  const u32x4_t v = __builtin_amdgcn_raw_buffer_load_b128(r, off, 0, 0);
+  return make_float4(__uint_as_float(v.x), __uint_as_float(v.y), __uint_as_float(v.z), __uint_as_float(v.w));
+}
+__device__ __forceinline__ void st64(__amdgpu_buffer_rsrc_t r, int off, unsigned a, unsigned b) {
+  __builtin_amdgcn_raw_buffer_store_b64((u32x2_t){a, b}, r, off, 0, 0);
+}
+__device__ __forceinline__ void st128f(__amdgpu_buffer_rsrc_t r, int off, float4 v) {
+  __builtin_amdgcn_raw_buffer_store_b128((u32x4_t){__float_as_uint(v.x), __float_as_uint(v.y), __float_as_uint(v.z), __float_as_uint(v.w)}, r, off, 0, 0);
+}
 
 // ---- epilogue on 4 consecutive output columns (gn .. gn+3) of row gm
 template <typename Tag, bool PRELOADED = false>
@@ -82,20 +116,6 @@ __device__ __forceinline__ void epilogue_quad(const GemmP& p, int gm, int gn, fl
   }
 }
 
-// GEGLU: `gn` = packed column of the value quad (gate quad is 8 packed columns further)
-template <typename Tag>
-__device__ __forceinline__ void epilogue_geglu(const GemmP& p, int gm, int gn, float (&val)[4], float (&gate)[4]) {
-  float v[4];
-#pragma unroll
-  for (int e = 0; e < 4; ++e) {
-    float a = val[e], g = gate[e];
-    if (p.bias) { a += p.bias[gn + e]; g += p.bias[gn + 8 + e]; }
-    v[e] = a * gelu_erf_f(g);
-  }
-  const int oc = (gn >> 4) * 8 + (gn & 7);
-  *(uint2*)(p.out + ((long)gm * p.ldo + oc) * 2) = make_uint2(pack2<Tag>(v[0], v[1]), pack2<Tag>(v[2], v[3]));
-}
-
 template <int N> __device__ __forceinline__ void wait_vmcnt() {
   asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
 }
@@ -123,6 +143,7 @@ template <typename Tag, int BM, int BN, int BK, int NST, int WGM, int WGN, int M
 __global__ __launch_bounds__(64 * WGM * WGN, gemm_min_waves(BM, BN, BK, NST, 64 * WGM * WGN))
 void gemm_kernel(const GemmP p) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
+  TL(0);
   constexpr int NT = 64 * WGM * WGN;                   // threads
   constexpr int CPR = BK / 8;                          // 16-byte chunks per tile row
   constexpr int ROWB = BK * 2;
@@ -305,6 +326,40 @@ void gemm_kernel(const GemmP p) {
       for (int j = 0; j < FN; ++j) acc[i][j] = Cvt<Tag>::mfma32(bf[j], af[i], acc[i][j]);
   };
 
+  // residual operands of every (row, quad) this lane will finish (epilogue layout, see below): ONE batch of loads.
+  // Tiles with register headroom issue it BEFORE the main loop so the whole K loop hides the latency; the 256-row
+  // tiles (128-VGPR budget) issue it at the top of the epilogue, where it overlaps the barrier and the LDS transposition.
+  // (The AlphaBlender source is usually the residual tensor itself -- temporal ResBlock -- and then shares the
+  // preloaded value; a distinct blend tensor is read in-pass.)
+  constexpr int NCH = (FN + 1) / 2;                    // 64-column chunks per fragment row
+  constexpr bool EARLY_RES = BM <= 128;
+  uint2 resv[EARLY_RES ? FM : 1][EARLY_RES ? NCH : 1][8];   // 256-row tiles read the residual inside the passes
+  const bool direct = (p.out_col_hw > 0 || p.out_f32) && p.splitk == 1;   // rare layouts keep the simple per-fragment path
+  const bool blend_is_res = p.blend && p.blend == p.residual && p.ld_blend == p.ld_res;
+  auto preload_residual = [&]() {
+    if constexpr (EARLY_RES) if (!direct && !p.geglu && p.splitk == 1) {
+      const __amdgpu_buffer_rsrc_t r_res = make_rsrc(p.residual, p.res_bytes);
+#pragma unroll
+      for (int i = 0; i < FM; ++i)
+#pragma unroll
+        for (int c = 0; c < NCH; ++c) {
+          const int nfr = (2 * c + 1 < FN) ? 2 : 1;
+          const int q_per_row = nfr * 8, rows_per_pass = 64 / q_per_row;
+          const int gn = n0 + wc * WTN + c * 64 + (lane % q_per_row) * 4;
+#pragma unroll
+          for (int pass = 0; pass < 8; ++pass) {
+            resv[i][c][pass] = make_uint2(0, 0);
+            if (pass * rows_per_pass < 32) {
+              const int gm = m0 + wr * WTM + i * 32 + pass * rows_per_pass + lane / q_per_row;
+              resv[i][c][pass] = ld64(r_res, (gm < p.m && gn < p.n) ? (int)(((long)gm * p.ld_res + gn) * 2) : kInv);
+            }
+          }
+        }
+    }
+  };
+  preload_residual();
+  TL(1);
+
   if constexpr (NST == 2) {
     // plain double buffer: wait tile kt, barrier, issue tile kt+1, compute tile kt
     stage(0);
@@ -312,6 +367,9 @@ void gemm_kernel(const GemmP p) {
       wait_vmcnt<0>();
       __builtin_amdgcn_s_barrier();
       asm volatile("" ::: "memory");
+#ifdef TT_GEMM_TIMELINE
+      if (kt == 0) TL(2);
+#endif
       if (kt + 1 < KT) stage((kt + 1) & 1);
       const char* sa = smem + (kt & 1) * STAGE;
 #pragma unroll
@@ -361,95 +419,161 @@ void gemm_kernel(const GemmP p) {
   // directly, one instruction would touch 32 rows x 16 bytes.  Instead each wave transposes its accumulators through a
   // private LDS strip (fp32, 32 rows x 64 columns at a time) and re-reads them so that 16 consecutive lanes cover 64
   // consecutive columns of one row: every residual/blend load and every store instruction then covers 4 rows x 128
-  // contiguous bytes.  The arithmetic (fp32, same order) is unchanged.
-  const bool direct = p.splitk > 1 || p.out_col_hw > 0;
+  // contiguous bytes.  All global accesses go through bounds-checked descriptors (see make_rsrc) so the pass loops are
+  // straight-line code; the arithmetic (fp32, same order) is what epilogue_quad does.
+  TL(3);
   if (!direct) {
-    constexpr int NCH = (FN + 1) / 2;                  // 64-column chunks per fragment row
-    // residual / blend operands of every (row, quad) this lane will finish: issued as ONE batch up front so their
-    // latency overlaps the barrier and the LDS transposition instead of serialising pass by pass
-    // (the AlphaBlender source is usually the residual tensor itself -- temporal ResBlock -- and then shares the
-    // preloaded value; a distinct blend tensor is read in-pass to keep the register budget at 2 waves per SIMD)
-    uint2 resv[FM][NCH][8];
-    const bool blend_is_res = p.blend && p.blend == p.residual && p.ld_blend == p.ld_res;
-    if (!p.geglu && p.residual) {
-#pragma unroll
-      for (int i = 0; i < FM; ++i)
-#pragma unroll
-        for (int c = 0; c < NCH; ++c) {
-          const int nfr = (2 * c + 1 < FN) ? 2 : 1;
-          const int q_per_row = nfr * 8, rows_per_pass = 64 / q_per_row;
-          const int gn = n0 + wc * WTN + c * 64 + (lane % q_per_row) * 4;
-#pragma unroll
-          for (int pass = 0; pass < 8; ++pass) {
-            resv[i][c][pass] = make_uint2(0, 0);
-            if (pass * rows_per_pass < 32) {
-              const int gm = m0 + wr * WTM + i * 32 + pass * rows_per_pass + lane / q_per_row;
-              if (gm < p.m && gn < p.n) resv[i][c][pass] = *(const uint2*)(p.residual + ((long)gm * p.ld_res + gn) * 2);
-            }
-          }
-        }
-    }
-    __syncthreads();                                   // all waves are done with the operand ring
+    const __amdgpu_buffer_rsrc_t r_bias = make_rsrc(p.bias, p.bias_bytes);
+    const __amdgpu_buffer_rsrc_t r_out = p.splitk > 1 ? make_rsrc(p.ws, p.ws_bytes) : make_rsrc(p.out, p.out_bytes);
     // strip = 32 rows x 256 bytes per wave, 16-byte quads XOR-swizzled by the row (no padding: 8 KiB per wave)
     auto strip_off = [](int row, int quad, int nq) { return row * 256 + ((quad ^ (row & (nq - 1))) << 4); };
     char* ebuf = smem + wid * 8192;
     static_assert(WGM * WGN * 8192 <= NST * STAGE, "epilogue strips do not fit the ring");
+    if (!p.geglu) {
+      // bias of the 4 columns this lane finishes in each 64-column chunk (row-independent: loaded once)
+      float4 bias4[NCH];
 #pragma unroll
-    for (int i = 0; i < FM; ++i) {
-      const int mb = m0 + wr * WTM + i * 32;
-      if (!p.geglu) {
+      for (int c = 0; c < NCH; ++c) {
+        const int q_per_row = ((2 * c + 1 < FN) ? 2 : 1) * 8;
+        const int gn = n0 + wc * WTN + c * 64 + (lane % q_per_row) * 4;
+        bias4[c] = ld128f(r_bias, gn < p.n ? gn * 4 : kInv);
+      }
+      const float alpha = p.blend ? p.alpha : 0.0f, one_m_alpha = 1.0f - alpha;
+      __syncthreads();                                 // all waves are done with the operand ring
+      TL(4);
+      // Operand variants (uniform dispatch, each straight-line):
+      //   FILM   the row vector (time-embedding FiLM term, one vector per rowvec_rows output rows) of the <= 2 row groups
+      //          a 32-row fragment spans is loaded up front and selected per row;
+      //   INPASS operands that cannot be held in registers are loaded inside the pass batches: a blend tensor distinct
+      //          from the residual, a row vector with groups shorter than 32 rows, and -- on the 256-row tiles, whose
+      //          128-VGPR budget has no room for the preload -- the residual.  A load issued after a store waits for
+      //          that store (in-order vmcnt), so each batch loads first and stores last; the planner keeps such
+      //          epilogues off the 256-row tiles.
+      auto run = [&](auto film_tag, auto inpass_tag) {
+        constexpr bool FILM = decltype(film_tag)::value, INPASS = decltype(inpass_tag)::value;
+        const __amdgpu_buffer_rsrc_t r_rv = make_rsrc(p.rowvec, (FILM || INPASS) ? p.rowvec_bytes : 0);
+        const __amdgpu_buffer_rsrc_t r_bl = make_rsrc(p.blend, INPASS ? p.blend_bytes : 0);
+        const __amdgpu_buffer_rsrc_t r_res = make_rsrc(p.residual, (INPASS && !EARLY_RES) ? p.res_bytes : 0);
+        const int rv_rows = p.rowvec ? p.rowvec_rows : 1;
 #pragma unroll
-        for (int jc = 0; jc < FN; jc += 2) {
-          constexpr int QMAX = 16;
-          const int nfr = (jc + 1 < FN) ? 2 : 1;       // fragments in this chunk (compile-time after unrolling)
+        for (int i = 0; i < FM; ++i) {
+          const int mb = m0 + wr * WTM + i * 32;
+          const int grp0 = mb / rv_rows;                 // row group of the fragment's first row (uniform)
+          const int grp_split = (grp0 + 1) * rv_rows;    // first row of the next group
 #pragma unroll
-          for (int jj = 0; jj < 2; ++jj) {
-            if (jc + jj < FN) {
-#pragma unroll
-              for (int g = 0; g < 4; ++g)
-                *(float4*)(ebuf + strip_off(l31, jj * 8 + 2 * g + hi, nfr * 8)) =
-                    make_float4(acc[i][jc + jj][g * 4], acc[i][jc + jj][g * 4 + 1], acc[i][jc + jj][g * 4 + 2], acc[i][jc + jj][g * 4 + 3]);
+          for (int jc = 0; jc < FN; jc += 2) {
+            const int nfr = (jc + 1 < FN) ? 2 : 1;       // fragments in this chunk (compile-time after unrolling)
+            const int q_per_row = nfr * 8;               // 4-column quads per strip row
+            const int rows_per_pass = 64 / q_per_row;
+            const int qq = lane % q_per_row, rr = lane / q_per_row;
+            const int gn = n0 + wc * WTN + jc * 32 + qq * 4;
+            const float4 b4 = bias4[jc / 2];
+            float4 film_lo = make_float4(0.f, 0.f, 0.f, 0.f), film_hi = film_lo;
+            if constexpr (FILM) {
+              film_lo = ld128f(r_rv, (mb < p.m && gn < p.n) ? (int)(((long)grp0 * p.ld_rowvec + gn) * 4) : kInv);
+              film_hi = ld128f(r_rv, (grp_split < p.m && gn < p.n) ? (int)(((long)(grp0 + 1) * p.ld_rowvec + gn) * 4) : kInv);
             }
-          }
-          const int q_per_row = nfr * 8;               // 4-column quads per strip row
-          const int rows_per_pass = 64 / q_per_row;
-          const int qq = lane % q_per_row, rr = lane / q_per_row;
-          const int gn = n0 + wc * WTN + jc * 32 + qq * 4;
 #pragma unroll
-          for (int pass = 0; pass < 32 * QMAX / 64; ++pass) {
-            if (pass * rows_per_pass < 32) {
-              const int r = pass * rows_per_pass + rr;
-              const float4 t = *(const float4*)(ebuf + strip_off(r, qq, q_per_row));
-              const int gm = mb + r;
-              if (gm < p.m && gn < p.n) {
-                float v[4] = {t.x, t.y, t.z, t.w};
-                const uint2 rq = resv[i][jc / 2][pass];
-                const uint2 bq = (p.blend && !blend_is_res) ? *(const uint2*)(p.blend + ((long)gm * p.ld_blend + gn) * 2) : rq;
-                epilogue_quad<Tag, true>(p, gm, gn, v, rq, bq);
+            for (int jj = 0; jj < 2; ++jj) {
+              if (jc + jj < FN) {
+#pragma unroll
+                for (int g = 0; g < 4; ++g)
+                  *(float4*)(ebuf + strip_off(l31, jj * 8 + 2 * g + hi, nfr * 8)) =
+                      make_float4(acc[i][jc + jj][g * 4], acc[i][jc + jj][g * 4 + 1], acc[i][jc + jj][g * 4 + 2], acc[i][jc + jj][g * 4 + 3]);
+              }
+            }
+            constexpr int PB = INPASS ? (BM > 128 ? 2 : 4) : 8;   // passes per batch, sized to the register budget
+#pragma unroll
+            for (int pb = 0; pb < 8; pb += PB) {
+              uint2 rqv[PB], blv[PB];
+              float4 rvv[PB];
+#pragma unroll
+              for (int k = 0; k < PB; ++k) {
+                const int pass = pb + k;
+                rqv[k] = blv[k] = make_uint2(0, 0);
+                rvv[k] = make_float4(0.f, 0.f, 0.f, 0.f);
+                if (pass * rows_per_pass < 32) {
+                  const int gm = mb + pass * rows_per_pass + rr;
+                  const bool ok = gm < p.m && gn < p.n;
+                  if constexpr (EARLY_RES) rqv[k] = resv[i][jc / 2][pass];
+                  else if constexpr (INPASS) rqv[k] = ld64(r_res, ok ? (int)(((long)gm * p.ld_res + gn) * 2) : kInv);
+                  if constexpr (INPASS) {
+                    rvv[k] = ld128f(r_rv, ok ? (int)(((long)(gm / rv_rows) * p.ld_rowvec + gn) * 4) : kInv);
+                    blv[k] = ld64(r_bl, ok ? (int)(((long)gm * p.ld_blend + gn) * 2) : kInv);
+                  }
+                }
+              }
+#pragma unroll
+              for (int k = 0; k < PB; ++k) {
+                const int pass = pb + k;
+                if (pass * rows_per_pass < 32) {
+                  const int r = pass * rows_per_pass + rr;
+                  const float4 t = *(const float4*)(ebuf + strip_off(r, qq, q_per_row));
+                  const int gm = mb + r;
+                  const bool ok = gm < p.m && gn < p.n;
+                  if (p.splitk > 1) {                    // uniform: fp32 partial sums of K slice `split`
+                    st128f(r_out, ok ? (int)((((long)split * p.m + gm) * p.n + gn) * 4) : kInv, t);
+                  } else {
+                    float v[4] = {(t.x + b4.x) * p.acc_scale, (t.y + b4.y) * p.acc_scale, (t.z + b4.z) * p.acc_scale,
+                                  (t.w + b4.w) * p.acc_scale};
+                    const uint2 rq = rqv[k];
+                    uint2 bq = rq;
+                    if constexpr (FILM) {
+                      const float4 f = gm >= grp_split ? film_hi : film_lo;
+                      v[0] += f.x; v[1] += f.y; v[2] += f.z; v[3] += f.w;
+                    }
+                    if constexpr (INPASS) {
+                      v[0] += rvv[k].x; v[1] += rvv[k].y; v[2] += rvv[k].z; v[3] += rvv[k].w;
+                      bq = (p.blend && !blend_is_res) ? blv[k] : rq;
+                    }
+                    float r4[4], b4v[4];
+                    unpack4<Tag>(rq, r4);
+                    unpack4<Tag>(bq, b4v);
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) v[e] = alpha * b4v[e] + one_m_alpha * (v[e] + r4[e]);
+                    st64(r_out, ok ? (int)(((long)gm * p.ldo + gn) * 2) : kInv, pack2<Tag>(v[0], v[1]), pack2<Tag>(v[2], v[3]));
+                  }
+                }
               }
             }
           }
         }
-      } else {
-        // GEGLU: value/gate pairs are lane-local (regs g=0/2 value, g=1/3 gate); gelu in registers, then the 16
-        // output columns of each fragment go through the strip: 2 fragments -> 32 output columns = 64 bytes per row.
+      };
+      const bool inpass = (p.blend && !blend_is_res) || (p.rowvec && p.rowvec_rows < 32) || (!EARLY_RES && p.residual);
+      if (inpass) run(std::false_type{}, std::true_type{});
+      else if (p.rowvec) run(std::true_type{}, std::false_type{});
+      else run(std::false_type{}, std::false_type{});
+    } else {
+      // GEGLU: value/gate pairs are lane-local (regs g=0/2 value, g=1/3 gate); gelu in registers, then the 16
+      // output columns of each fragment go through the strip: 2 fragments -> 32 output columns = 64 bytes per row.
+      float4 bval[FN][2], bgate[FN][2];                  // bias of this lane's value / gate quads (row-independent)
+#pragma unroll
+      for (int j = 0; j < FN; ++j)
+#pragma unroll
+        for (int tt = 0; tt < 2; ++tt) {
+          const int gnp = n0 + wc * WTN + j * 32 + tt * 16 + 4 * hi;      // packed column of the value quad
+          bval[j][tt] = ld128f(r_bias, gnp < p.n ? gnp * 4 : kInv);
+          bgate[j][tt] = ld128f(r_bias, gnp < p.n ? (gnp + 8) * 4 : kInv);
+        }
+      __syncthreads();                                 // all waves are done with the operand ring
+      TL(4);
+#pragma unroll
+      for (int i = 0; i < FM; ++i) {
+        const int mb = m0 + wr * WTM + i * 32;
 #pragma unroll
         for (int jc = 0; jc < FN; jc += 2) {
           const int nfr = (jc + 1 < FN) ? 2 : 1;
 #pragma unroll
           for (int jj = 0; jj < 2; ++jj) {
             if (jc + jj < FN) {
-              const int nb = n0 + wc * WTN + (jc + jj) * 32;
 #pragma unroll
               for (int tt = 0; tt < 2; ++tt) {
-                const int gnp = nb + tt * 16 + 4 * hi;            // packed column of the value quad
+                const float4 bv = bval[jc + jj][tt], bg = bgate[jc + jj][tt];
+                const float bvv[4] = {bv.x, bv.y, bv.z, bv.w}, bgv[4] = {bg.x, bg.y, bg.z, bg.w};
                 float v[4];
 #pragma unroll
-                for (int e = 0; e < 4; ++e) {
-                  float a = acc[i][jc + jj][(2 * tt) * 4 + e], g2 = acc[i][jc + jj][(2 * tt + 1) * 4 + e];
-                  if (p.bias && gnp < p.n) { a += p.bias[gnp + e]; g2 += p.bias[gnp + 8 + e]; }
-                  v[e] = a * gelu_erf_f(g2);
-                }
+                for (int e = 0; e < 4; ++e)
+                  v[e] = (acc[i][jc + jj][(2 * tt) * 4 + e] + bvv[e]) * gelu_erf_f(acc[i][jc + jj][(2 * tt + 1) * 4 + e] + bgv[e]);
                 *(float4*)(ebuf + strip_off(l31, jj * 4 + tt * 2 + hi, nfr * 4)) = make_float4(v[0], v[1], v[2], v[3]);
               }
             }
@@ -464,16 +588,20 @@ void gemm_kernel(const GemmP p) {
               const int r = pass * rows_per_pass + rr;
               const float4 t = *(const float4*)(ebuf + strip_off(r, qq, q_per_row));
               const int gm = mb + r;
-              if (gm < p.m && oc * 2 < p.n)
-                *(uint2*)(p.out + ((long)gm * p.ldo + oc) * 2) = make_uint2(pack2<Tag>(t.x, t.y), pack2<Tag>(t.z, t.w));
+              st64(r_out, (gm < p.m && oc * 2 < p.n) ? (int)(((long)gm * p.ldo + oc) * 2) : kInv,
+                   pack2<Tag>(t.x, t.y), pack2<Tag>(t.z, t.w));
             }
           }
         }
       }
     }
+#ifdef TT_GEMM_TIMELINE
+    __builtin_amdgcn_s_waitcnt(0);
+    TL(5);
+#endif
     return;
   }
-  // direct path: split-K slabs and the padded transposed output
+  // direct path: fp32 output and the padded transposed output (never combined with split-K: see tt_gemm)
 #pragma unroll
   for (int i = 0; i < FM; ++i) {
     const int gm = m0 + wr * WTM + i * 32 + l31;
@@ -481,15 +609,6 @@ void gemm_kernel(const GemmP p) {
 #pragma unroll
     for (int j = 0; j < FN; ++j) {
       const int nb = n0 + wc * WTN + j * 32;
-      if (p.splitk > 1) {
-        float* slab = p.ws + ((long)split * p.m + gm) * p.n;
-#pragma unroll
-        for (int g = 0; g < 4; ++g) {
-          const int gn = nb + 8 * g + 4 * hi;
-          if (gn < p.n) *(float4*)(slab + gn) = make_float4(acc[i][j][g * 4], acc[i][j][g * 4 + 1], acc[i][j][g * 4 + 2], acc[i][j][g * 4 + 3]);
-        }
-        continue;
-      }
 #pragma unroll
       for (int g = 0; g < 4; ++g) {
         const int gn = nb + 8 * g + 4 * hi;
@@ -578,6 +697,10 @@ constexpr TileCfg kCfgs[] = {
   {128, 128, 32, 2, 2, 2},   // 19: 4 waves, 32 KiB
   {256, 160, 32, 3, 8, 1},   // 20: N = 320/960, 8 waves (wave tile 32x160), 78 KiB -> 2 blocks/CU
   {256, 128, 32, 4, 4, 2},   // 21: like 3 with one more stage (96 KiB, 1 block/CU)
+  {128, 128, 32, 4, 4, 2},   // 22: 8 waves, 64 KiB, prefetch distance 3 (x32) -> 2 blocks/CU
+  {128, 128, 32, 5, 4, 2},   // 23: 8 waves, 80 KiB, prefetch distance 4 (x32) -> 2 blocks/CU
+  {128, 128, 64, 3, 4, 2},   // 24: 8 waves, 96 KiB, prefetch distance 2 -> 1 block/CU
+  {128, 128, 64, 4, 4, 2},   // 25: 8 waves, 128 KiB, prefetch distance 3 -> 1 block/CU
 };
 constexpr int kNumCfgs = sizeof(kCfgs) / sizeof(kCfgs[0]);
 
@@ -600,14 +723,17 @@ int forced_split() {
 //   * few tiles but a long K (convs at the two coarsest levels): 128x128 tiles with the K loop split over S
 //     workgroups, fp32 slabs reduced in fixed order by a second kernel.
 struct Plan { int cfg, splitk; };
-Plan make_plan(int m, int n, long ktot, bool allow_split) {
+// `wide_ok`: the 256x128 tile pays for the GEGLU projections (measured: 125 vs 156 us on 50176x2560x320); with any other
+// epilogue the 8-wave 128x128 tile is as fast or faster, and epilogues that read per-row tensors (residual / blend / row
+// vector) would have to read them between the stores there (128-VGPR budget, see the epilogue)
+Plan make_plan(int m, int n, long ktot, bool allow_split, bool wide_ok = true) {
   Plan pl{0, 1};
   const int f = forced_cfg();
   const long b128 = (long)ceil_div(m, 128) * ceil_div(n, 128);
   const long b12864 = (long)ceil_div(m, 128) * ceil_div(n, 64);
   if (f >= 0 && f < kNumCfgs) pl.cfg = f;
   else if (n % 160 == 0 && n % 128 != 0 && n <= 960 && m >= 2048) pl.cfg = 10;
-  else if (m >= 8192 && n >= 1024) pl.cfg = 3;
+  else if (m >= 8192 && n >= 1024 && wide_ok) pl.cfg = 3;
   else if (m < 2048 && n >= 2560 && n % 160 == 0) pl.cfg = 10;
   else if (b128 >= 384) pl.cfg = 18;                 // 128x128 with 8 waves (32x64 wave tiles): 16 waves per CU
   else if (b12864 >= 384) pl.cfg = 1;
@@ -648,11 +774,19 @@ void launch(GemmP& p, int cfg, hipStream_t st) {
     case 18: launch_cfg<Tag, 128, 128, 64, 2, 4, 2>(p, st); break;
     case 19: launch_cfg<Tag, 128, 128, 32, 2, 2, 2>(p, st); break;
     case 20: launch_cfg<Tag, 256, 160, 32, 3, 8, 1>(p, st); break;
-    default: launch_cfg<Tag, 256, 128, 32, 4, 4, 2>(p, st); break;
+    case 21: launch_cfg<Tag, 256, 128, 32, 4, 4, 2>(p, st); break;
+    case 22: launch_cfg<Tag, 128, 128, 32, 4, 4, 2>(p, st); break;
+    case 23: launch_cfg<Tag, 128, 128, 32, 5, 4, 2>(p, st); break;
+    case 24: launch_cfg<Tag, 128, 128, 64, 3, 4, 2>(p, st); break;
+    default: launch_cfg<Tag, 128, 128, 64, 4, 4, 2>(p, st); break;
   }
 }
 
 }  // namespace
+
+#ifdef TT_GEMM_TIMELINE
+extern "C" int tt_debug_timeline(long long* host, int n) { return (int)hipMemcpyFromSymbol(host, HIP_SYMBOL(g_tl), n * 8); }
+#endif
 
 extern "C" int tt_gemm_set_tile_override(int32_t cfg) {
   if (cfg < -1 || cfg >= kNumCfgs) TT_FAIL(TT_EINVAL, "tt_gemm_set_tile_override: cfg %d (valid -1..%d)", cfg, kNumCfgs - 1);
@@ -663,13 +797,13 @@ extern "C" int tt_gemm_set_tile_override(int32_t cfg) {
 static Plan plan_for(const TtGemmArgs* a) {
   const int taps = a->mode == 1 ? 9 : (a->mode == 2 ? 3 : 1);
   const bool allow = !a->geglu;
-  return make_plan(a->m, a->n, (long)taps * (a->k0 + a->k1), allow);
+  return make_plan(a->m, a->n, (long)taps * (a->k0 + a->k1), allow, a->geglu != 0);
 }
 
 extern "C" int tt_gemm_plan(const TtGemmArgs* a, int32_t* bm, int32_t* bn) {
   if (!a || !bm || !bn || a->m <= 0 || a->n <= 0) TT_FAIL(TT_EINVAL, "tt_gemm_plan: bad arguments");
   Plan pl = plan_for(a);
-  if (pl.splitk > 1 && (!a->ws || (size_t)a->ws_bytes < (size_t)pl.splitk * a->m * a->n * sizeof(float))) pl = Plan{make_plan(a->m, a->n, 0, false).cfg, 1};
+  if (pl.splitk > 1 && (!a->ws || (size_t)a->ws_bytes < (size_t)pl.splitk * a->m * a->n * sizeof(float))) pl = Plan{make_plan(a->m, a->n, 0, false, a->geglu != 0).cfg, 1};
   *bm = kCfgs[pl.cfg].bm; *bn = kCfgs[pl.cfg].bn;
   return TT_OK;
 }
@@ -719,12 +853,25 @@ extern "C" int tt_gemm(const TtGemmArgs* a, tt_stream_t stream) {
     if (a0b >= (1L << 31) || a1b >= (1L << 31) || wb >= (1L << 31))
       TT_FAIL(TT_EUNSUPPORTED, "tt_gemm: operand larger than 2 GiB (32-bit buffer offsets)");
     p.a0_bytes = (unsigned)a0b; p.a1_bytes = (unsigned)a1b; p.w_bytes = (unsigned)wb;
+    // epilogue operands (bounds-checked descriptors; 0 bytes = absent -> loads return 0)
+    const long n_out = p.geglu ? p.n / 2 : p.n;
+    const long outb = ((long)(p.m - 1) * p.ldo + (p.out_col_hw > 0 ? p.ldo : n_out)) * (p.out_f32 ? 4 : 2);
+    const long resb = p.residual ? ((long)(p.m - 1) * p.ld_res + p.n) * 2 : 0;
+    const long blb = p.blend ? ((long)(p.m - 1) * p.ld_blend + p.n) * 2 : 0;
+    const long rvb = p.rowvec ? ((long)((p.m - 1) / p.rowvec_rows) * p.ld_rowvec + p.n) * 4 : 0;
+    if (outb >= (1L << 31) || resb >= (1L << 31) || blb >= (1L << 31) || rvb >= (1L << 31))
+      TT_FAIL(TT_EUNSUPPORTED, "tt_gemm: epilogue operand larger than 2 GiB (32-bit buffer offsets)");
+    p.out_bytes = (unsigned)outb; p.res_bytes = (unsigned)resb; p.blend_bytes = (unsigned)blb;
+    p.bias_bytes = p.bias ? (unsigned)p.n * 4u : 0u; p.rowvec_bytes = (unsigned)rvb; p.ws_bytes = 0;
   }
   Plan pl = plan_for(a);
   if (pl.splitk > 1 && (!a->ws || (size_t)a->ws_bytes < (size_t)pl.splitk * a->m * a->n * sizeof(float)))
-    pl = Plan{make_plan(a->m, a->n, 0, false).cfg, 1};            // no workspace: un-split plan (still correct)
+    pl = Plan{make_plan(a->m, a->n, 0, false, a->geglu != 0).cfg, 1};            // no workspace: un-split plan (still correct)
+  if (pl.splitk > 1 && (long)pl.splitk * a->m * a->n * 4 >= (1L << 31))
+    pl = Plan{make_plan(a->m, a->n, 0, false, a->geglu != 0).cfg, 1};            // slabs beyond the 32-bit offsets: un-split plan
   p.splitk = pl.splitk;
   p.ws = (float*)a->ws;
+  p.ws_bytes = pl.splitk > 1 ? (unsigned)((long)pl.splitk * a->m * a->n * 4) : 0u;
   hipStream_t st = (hipStream_t)stream;
   if (a->dtype == TT_BF16) launch<bf16_tag>(p, pl.cfg, st); else launch<f16_tag>(p, pl.cfg, st);
   TT_CHECK_LAUNCH("tt_gemm");
