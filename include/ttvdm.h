@@ -77,9 +77,10 @@ typedef struct TtGemmArgs {
   void* ws; int64_t ws_bytes;          /* optional caller-owned scratch for split-K (tt_gemm_ws_bytes); NULL = never split */
 } TtGemmArgs;
 int tt_gemm(const TtGemmArgs* args, tt_stream_t stream);
-/* which BM x BN workgroup tile tt_gemm will use for (m, n): lets a profiler name the kernel instance
- * (gemm_kernel<dtype,BM,BN,2,2,mode>) a launch maps to.  Host-only, no launch. */
-int tt_gemm_plan(const TtGemmArgs* args, int32_t* bm, int32_t* bn);
+/* which tile configuration tt_gemm will use for this problem: cfg[0..6] = BM, BN, BK, ring stages, waves along M,
+ * waves along N, split-K factor.  Lets a profiler name the kernel instance
+ * (gemm_kernel<dtype, BM, BN, BK, stages, wavesM, wavesN, mode>) a launch maps to.  Host-only, no launch. */
+int tt_gemm_plan(const TtGemmArgs* args, int32_t cfg[7]);
 /* bytes of fp32 scratch tt_gemm would like for this problem (0 = no split-K planned).  Problems with few output
  * tiles and a long K (convs at the coarsest UNet levels) are split over K; the slabs are summed in a fixed order,
  * so results stay bit-reproducible.  Without (enough) workspace the un-split plan runs instead. */

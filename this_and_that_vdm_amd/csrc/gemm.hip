@@ -800,11 +800,14 @@ static Plan plan_for(const TtGemmArgs* a) {
   return make_plan(a->m, a->n, (long)taps * (a->k0 + a->k1), allow, a->geglu != 0);
 }
 
-extern "C" int tt_gemm_plan(const TtGemmArgs* a, int32_t* bm, int32_t* bn) {
-  if (!a || !bm || !bn || a->m <= 0 || a->n <= 0) TT_FAIL(TT_EINVAL, "tt_gemm_plan: bad arguments");
+extern "C" int tt_gemm_plan(const TtGemmArgs* a, int32_t cfg[7]) {
+  if (!a || !cfg || a->m <= 0 || a->n <= 0) TT_FAIL(TT_EINVAL, "tt_gemm_plan: bad arguments");
   Plan pl = plan_for(a);
-  if (pl.splitk > 1 && (!a->ws || (size_t)a->ws_bytes < (size_t)pl.splitk * a->m * a->n * sizeof(float))) pl = Plan{make_plan(a->m, a->n, 0, false, a->geglu != 0).cfg, 1};
-  *bm = kCfgs[pl.cfg].bm; *bn = kCfgs[pl.cfg].bn;
+  if (pl.splitk > 1 && (!a->ws || (size_t)a->ws_bytes < (size_t)pl.splitk * a->m * a->n * sizeof(float) ||
+                        (long)pl.splitk * a->m * a->n * 4 >= (1L << 31)))
+    pl = Plan{make_plan(a->m, a->n, 0, false, a->geglu != 0).cfg, 1};
+  const TileCfg& t = kCfgs[pl.cfg];
+  cfg[0] = t.bm; cfg[1] = t.bn; cfg[2] = t.bk; cfg[3] = t.nst; cfg[4] = t.wgm; cfg[5] = t.wgn; cfg[6] = pl.splitk;
   return TT_OK;
 }
 

@@ -119,11 +119,11 @@ def gemm(a0: torch.Tensor, w: torch.Tensor, *, a1: Optional[torch.Tensor] = None
     ev = _prof_begin()
     check(lib.tt_gemm(C.byref(g), _stream()), "tt_gemm")
     if ev is not None:
-        bm, bn = C.c_int32(), C.c_int32()
-        lib.tt_gemm_plan(C.byref(g), C.byref(bm), C.byref(bn))
+        cfg = (C.c_int32 * 7)()
+        lib.tt_gemm_plan(C.byref(g), cfg)
         taps = 9 if mode == 1 else (3 if mode == 2 else 1)
         tag = "bf16_tag" if g.dtype == TT_BF16 else "f16_tag"
-        _prof_end(ev, f"gemm_kernel<{tag},{bm.value},{bn.value},2,2,{mode}>", 2.0 * g.m * n * taps * (g.k0 + g.k1),
+        _prof_end(ev, f"gemm_kernel<{tag}, {', '.join(str(v) for v in cfg[:6])}, {mode}>", 2.0 * g.m * n * taps * (g.k0 + g.k1),
                   shape=(mode, g.m, n, taps * (g.k0 + g.k1), int(geglu), int(residual is not None)))
     return out
 
@@ -144,7 +144,7 @@ def attention(q, k, vt, out, *, nseq, lq, heads, head_dim, mask, lk, k_seq_strid
     if ev is not None:
         tag = "bf16_tag" if a.dtype == TT_BF16 else "f16_tag"
         keys = lk * (ctx_batches if mask == 2 else 1)
-        _prof_end(ev, f"attn_kernel<{tag},{head_dim},{mask}>", 4.0 * nseq * heads * lq * lk * head_dim,
+        _prof_end(ev, f"attn_kernel<{tag}, {head_dim}, {mask}>", 4.0 * nseq * heads * lq * lk * head_dim,
                   shape=("attn", nseq * heads, lq, lk, mask, 0))
     return out
 
