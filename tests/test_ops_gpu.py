@@ -300,7 +300,7 @@ def test_errors_are_loud(ops):
         ops.gemm(torch.zeros(8, 16, dtype=torch.float16), torch.zeros(8, 16, dtype=torch.float16))
 
 
-@pytest.mark.parametrize("cfg", list(range(22)))
+@pytest.mark.parametrize("cfg", list(range(26)))
 def test_gemm_every_tile_configuration(ops, cfg):
     """each entry of the tile table in gemm.hip, forced, on a ragged linear and a 2-source conv (bf16)."""
     from this_and_that_vdm_amd import _lib
@@ -324,6 +324,26 @@ def test_gemm_every_tile_configuration(ops, cfg):
         close(out, ref.permute(0, 2, 3, 1).reshape(-1, cout), dtype)
     finally:
         lib.tt_gemm_set_tile_override(-1)
+
+
+@pytest.mark.parametrize("n,rowvec", [(160, False), (128, False), (320, True)])
+def test_gemm_tall_short_k(ops, n, rowvec):
+    """the model's tall, short-K linears (M ~ 1e5, K = 64): ragged last tile, FiLM row vector spanning tile boundaries,
+    nothing written behind the last row."""
+    dtype = torch.bfloat16
+    m, k = 784 * 128 - 37, 64
+    a, w = rnd(m, k, dtype=dtype, seed=1), rnd(n, k, dtype=dtype, seed=2, scale=k ** -0.5)
+    bias, res = rnd(n, dtype=torch.float32, seed=3), rnd(m, n, dtype=dtype, seed=5)
+    kw, ref = {}, a.float() @ w.float().T + bias
+    if rowvec:
+        rows_per = 1792
+        rv = rnd((m + rows_per - 1) // rows_per, n, dtype=torch.float32, seed=4)
+        kw = dict(rowvec=rv.cuda(), rowvec_rows=rows_per)
+        ref = ref + rv.repeat_interleave(rows_per, 0)[:m]
+    out = torch.full((m + 8, n), 7.0, dtype=dtype, device="cuda")         # canary rows behind the output
+    ops.gemm(a.cuda(), w.cuda(), bias=bias.cuda(), residual=res.cuda(), out=out[:m], **kw)
+    close(out[:m], ref + res.float(), dtype, scale=2.0)
+    assert (out[m:] == 7.0).all()
 
 
 @pytest.mark.parametrize("dtype", DTYPES)

@@ -723,9 +723,9 @@ int forced_split() {
 //   * few tiles but a long K (convs at the two coarsest levels): 128x128 tiles with the K loop split over S
 //     workgroups, fp32 slabs reduced in fixed order by a second kernel.
 struct Plan { int cfg, splitk; };
-// `wide_ok`: the 256x128 tile pays for the GEGLU projections (measured: 125 vs 156 us on 50176x2560x320); with any other
-// epilogue the 8-wave 128x128 tile is as fast or faster, and epilogues that read per-row tensors (residual / blend / row
-// vector) would have to read them between the stores there (128-VGPR budget, see the epilogue)
+// `wide_ok`: the 256x128 tile pays for tall-and-wide problems (GEGLU projections, fused QKV) unless the epilogue reads
+// per-row tensors (residual / blend / row vector): its 128-VGPR budget has no room to preload them, so they would be read
+// between the stores (measured: 16 us epilogue instead of 3)
 Plan make_plan(int m, int n, long ktot, bool allow_split, bool wide_ok = true) {
   Plan pl{0, 1};
   const int f = forced_cfg();
@@ -797,7 +797,7 @@ extern "C" int tt_gemm_set_tile_override(int32_t cfg) {
 static Plan plan_for(const TtGemmArgs* a) {
   const int taps = a->mode == 1 ? 9 : (a->mode == 2 ? 3 : 1);
   const bool allow = !a->geglu;
-  return make_plan(a->m, a->n, (long)taps * (a->k0 + a->k1), allow, a->geglu != 0);
+  return make_plan(a->m, a->n, (long)taps * (a->k0 + a->k1), allow, !(a->residual || a->blend || a->rowvec));
 }
 
 extern "C" int tt_gemm_plan(const TtGemmArgs* a, int32_t cfg[7]) {
@@ -805,7 +805,7 @@ extern "C" int tt_gemm_plan(const TtGemmArgs* a, int32_t cfg[7]) {
   Plan pl = plan_for(a);
   if (pl.splitk > 1 && (!a->ws || (size_t)a->ws_bytes < (size_t)pl.splitk * a->m * a->n * sizeof(float) ||
                         (long)pl.splitk * a->m * a->n * 4 >= (1L << 31)))
-    pl = Plan{make_plan(a->m, a->n, 0, false, a->geglu != 0).cfg, 1};
+    pl = Plan{make_plan(a->m, a->n, 0, false, !(a->residual || a->blend || a->rowvec)).cfg, 1};
   const TileCfg& t = kCfgs[pl.cfg];
   cfg[0] = t.bm; cfg[1] = t.bn; cfg[2] = t.bk; cfg[3] = t.nst; cfg[4] = t.wgm; cfg[5] = t.wgn; cfg[6] = pl.splitk;
   return TT_OK;
@@ -869,9 +869,9 @@ extern "C" int tt_gemm(const TtGemmArgs* a, tt_stream_t stream) {
   }
   Plan pl = plan_for(a);
   if (pl.splitk > 1 && (!a->ws || (size_t)a->ws_bytes < (size_t)pl.splitk * a->m * a->n * sizeof(float)))
-    pl = Plan{make_plan(a->m, a->n, 0, false, a->geglu != 0).cfg, 1};            // no workspace: un-split plan (still correct)
+    pl = Plan{make_plan(a->m, a->n, 0, false, !(a->residual || a->blend || a->rowvec)).cfg, 1};            // no workspace: un-split plan (still correct)
   if (pl.splitk > 1 && (long)pl.splitk * a->m * a->n * 4 >= (1L << 31))
-    pl = Plan{make_plan(a->m, a->n, 0, false, a->geglu != 0).cfg, 1};            // slabs beyond the 32-bit offsets: un-split plan
+    pl = Plan{make_plan(a->m, a->n, 0, false, !(a->residual || a->blend || a->rowvec)).cfg, 1};            // slabs beyond the 32-bit offsets: un-split plan
   p.splitk = pl.splitk;
   p.ws = (float*)a->ws;
   p.ws_bytes = pl.splitk > 1 ? (unsigned)((long)pl.splitk * a->m * a->n * 4) : 0u;
