@@ -5,7 +5,15 @@
 namespace {
 
 constexpr int GN_GROUPS = 32;
-constexpr int GN_ROWS_PER_CHUNK = 128;
+// rows of one image a partial-statistics block covers: 8 per thread row-lane (two rounds of 4 loads in flight).  With a
+// fixed 128 rows the wide levels (C = 1280: one row-lane per block) walked 128 rows serially and launched 28 blocks:
+// 12 us per call whatever the tensor size.
+__host__ __device__ inline int gn_rows_per_chunk(int C) {
+  int rpb = 256 / (C >> 3);
+  if (rpb < 1) rpb = 1;
+  const int rows = rpb * 8;
+  return rows > 128 ? 128 : rows;
+}
 
 // partial sums per (image, row-chunk, group): ws[((img*chunks + chunk)*32 + g)*2 + {0,1}] (double)
 template <typename Tag>
@@ -19,7 +27,8 @@ __global__ void gn_partial_kernel(const char* x0, int c0, const char* x1, int c1
   float* psum = (float*)smem;            // [rpb][C]
   float* psq = psum + rpb * C;           // [rpb][C]
   const int myv = tid % cv, myr = tid / cv;
-  const int r0 = chunk * GN_ROWS_PER_CHUNK, r1 = min(hw, r0 + GN_ROWS_PER_CHUNK);
+  const int rows_per_chunk = gn_rows_per_chunk(C);
+  const int r0 = chunk * rows_per_chunk, r1 = min(hw, r0 + rows_per_chunk);
   if (myr < rpb) {
     float s[8], q[8];
 #pragma unroll
@@ -64,12 +73,14 @@ __global__ void gn_partial_kernel(const char* x0, int c0, const char* x1, int c1
 }
 
 // one block per statistics group-set: (image-group ig) -> images [ig*fpg, (ig+1)*fpg).
-// 256 threads = 32 groups x 8 slices; each slice sums a strided subset of the (frame, chunk) partials, then the
-// 8 slices are combined in a fixed order (deterministic).
-__global__ __launch_bounds__(256) void gn_finalize_kernel(const double* ws, int chunks, int hw, int C, int fpg,
+// 1024 threads = 32 groups x 32 slices; each slice sums a strided subset of the (frame, chunk) partials, then the
+// 32 slices are combined in a fixed order (deterministic).  (The cross-frame statistics of the temporal ResBlocks reduce
+// frames x chunks ~ 500 partials in 2 blocks: the slice count is what bounds this kernel's latency.)
+constexpr int GN_SLICES = 32;
+__global__ __launch_bounds__(1024) void gn_finalize_kernel(const double* ws, int chunks, int hw, int C, int fpg,
                                                           const float* gamma, const float* beta, float eps,
                                                           float* scale, float* shift) {
-  __shared__ double s_a[8][GN_GROUPS], s_b[8][GN_GROUPS];
+  __shared__ double s_a[GN_SLICES][GN_GROUPS], s_b[GN_SLICES][GN_GROUPS];
   __shared__ float s_mean[GN_GROUPS], s_rstd[GN_GROUPS];
   const int ig = blockIdx.x, tid = threadIdx.x;
   const int g = tid & 31, slice = tid >> 5;
@@ -77,7 +88,7 @@ __global__ __launch_bounds__(256) void gn_finalize_kernel(const double* ws, int 
     double a = 0.0, b = 0.0;
     const int total = fpg * chunks;
     const double* base = ws + ((long)ig * fpg * chunks) * GN_GROUPS * 2;
-    for (int i = slice; i < total; i += 8) {
+    for (int i = slice; i < total; i += GN_SLICES) {
       const double* o = base + ((long)i * GN_GROUPS + g) * 2;
       a += o[0]; b += o[1];
     }
@@ -87,7 +98,7 @@ __global__ __launch_bounds__(256) void gn_finalize_kernel(const double* ws, int 
   if (tid < GN_GROUPS) {
     double a = 0.0, b = 0.0;
 #pragma unroll
-    for (int s = 0; s < 8; ++s) { a += s_a[s][tid]; b += s_b[s][tid]; }
+    for (int s = 0; s < GN_SLICES; ++s) { a += s_a[s][tid]; b += s_b[s][tid]; }
     const double cnt = (double)fpg * hw * (C / GN_GROUPS);
     const double mean = a / cnt;
     double var = b / cnt - mean * mean;
@@ -188,8 +199,9 @@ __global__ __launch_bounds__(256) void ln_kernel(const char* x, long ldx, int ro
 }  // namespace
 
 extern "C" size_t tt_groupnorm_ws_bytes(int32_t nimg, int32_t hw, int32_t c) {
-  (void)c;
-  const long chunks = (hw + GN_ROWS_PER_CHUNK - 1) / GN_ROWS_PER_CHUNK;
+  if (c < 8) c = 8;
+  const int rows = gn_rows_per_chunk(c);
+  const long chunks = (hw + rows - 1) / rows;
   return (size_t)nimg * chunks * GN_GROUPS * 2 * sizeof(double);
 }
 
@@ -205,7 +217,8 @@ extern "C" int tt_groupnorm_stats(const void* x0, int32_t c0, const void* x1, in
   if (dtype != TT_BF16 && dtype != TT_F16) TT_FAIL(TT_EINVAL, "tt_groupnorm_stats: bad dtype");
   const int cv = C >> 3;
   if (cv > 1024) TT_FAIL(TT_EUNSUPPORTED, "tt_groupnorm_stats: C=%d too wide", C);
-  const int chunks = (hw + GN_ROWS_PER_CHUNK - 1) / GN_ROWS_PER_CHUNK;
+  const int rows_per_chunk = gn_rows_per_chunk(C);
+  const int chunks = (hw + rows_per_chunk - 1) / rows_per_chunk;
   int rpb = 256 / cv; if (rpb < 1) rpb = 1;
   int threads = cv * rpb; if (threads < GN_GROUPS) threads = GN_GROUPS;
   threads = (threads + 63) / 64 * 64;
@@ -215,7 +228,7 @@ extern "C" int tt_groupnorm_stats(const void* x0, int32_t c0, const void* x1, in
     hipLaunchKernelGGL(gn_partial_kernel<bf16_tag>, dim3(chunks, nimg), dim3(threads), lds, st, (const char*)x0, c0, (const char*)x1, c1, hw, chunks, (double*)ws);
   else
     hipLaunchKernelGGL(gn_partial_kernel<f16_tag>, dim3(chunks, nimg), dim3(threads), lds, st, (const char*)x0, c0, (const char*)x1, c1, hw, chunks, (double*)ws);
-  hipLaunchKernelGGL(gn_finalize_kernel, dim3(nimg / fpg), dim3(256), 0, st, (const double*)ws, chunks, hw, C, fpg, gamma, beta, eps, scale, shift);
+  hipLaunchKernelGGL(gn_finalize_kernel, dim3(nimg / fpg), dim3(32 * GN_SLICES), 0, st, (const double*)ws, chunks, hw, C, fpg, gamma, beta, eps, scale, shift);
   TT_CHECK_LAUNCH("tt_groupnorm_stats");
   return TT_OK;
 }
