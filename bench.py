@@ -242,6 +242,7 @@ def main():
         }
         print(json.dumps(out))
     if world > 1:
+        torch.distributed.barrier()          # rank 0 profiles after the timed region; leave together
         torch.distributed.destroy_process_group()
 
 
