@@ -88,6 +88,10 @@ size_t tt_gemm_ws_bytes(const TtGemmArgs* args);
 /* tuning knob: force tile configuration `cfg` (index into the table in gemm.hip) for every tt_gemm call of this
  * process; -1 restores the built-in heuristic.  Also settable by the TT_GEMM_CFG environment variable. */
 int tt_gemm_set_tile_override(int32_t cfg);
+/* tuning knob: route the 320 x 320 linears with m >= 4096 (mode 0, one source, bias / residual / self-blend epilogue) to
+ * the persistent W-in-registers streaming kernel.  Off by default (faster alone, slower next to a concurrent branch);
+ * also settable by TT_GEMM_SQ320=1. */
+int tt_gemm_set_streaming_square(int32_t on);
 
 /* ------------------------------------------------------------------------------------------------
  * tt_attention: softmax(Q K^T / sqrt(d)) V with online softmax on MFMA tiles; replaces

@@ -326,6 +326,51 @@ def test_gemm_every_tile_configuration(ops, cfg):
         lib.tt_gemm_set_tile_override(-1)
 
 
+@pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("m", [4101, 50176, 3 * 8192 - 31])
+@pytest.mark.parametrize("epi", ["plain", "bias_res", "blend"])
+def test_gemm_square_320_streaming_kernel(ops, dtype, m, epi):
+    """the W-in-registers persistent kernel that serves the 320 x 320 linears of the finest level (M >= 4096)."""
+    import ctypes as C
+    from this_and_that_vdm_amd import _lib
+    k = n = 320
+    a, w = rnd(m, k, dtype=dtype, seed=1), rnd(n, k, dtype=dtype, seed=2, scale=k ** -0.5)
+    bias, res = rnd(n, dtype=torch.float32, seed=3), rnd(m, n, dtype=dtype, seed=5)
+    lib = _lib.load()
+    try:
+        assert lib.tt_gemm_set_streaming_square(1) == 0
+        _run_square_320(ops, lib, dtype, m, epi, a, w, bias, res)
+    finally:
+        lib.tt_gemm_set_streaming_square(0)
+
+
+def _run_square_320(ops, lib, dtype, m, epi, a, w, bias, res):
+    import ctypes as C
+    from this_and_that_vdm_amd import _lib
+    k = n = 320
+    g = _lib.TtGemmArgs()
+    g.m, g.n, g.k0, g.mode = m, n, k, 0
+    cfg = (C.c_int32 * 7)()
+    assert lib.tt_gemm_plan(C.byref(g), cfg) == 0 and cfg[0] == 32 and cfg[1] == 320, list(cfg)
+    out = torch.full((m + 8, n), 7.0, dtype=dtype, device="cuda")
+    ref = a.float() @ w.float().T
+    if epi == "plain":
+        ops.gemm(a.cuda(), w.cuda(), out=out[:m])
+    elif epi == "bias_res":
+        ops.gemm(a.cuda(), w.cuda(), bias=bias.cuda(), acc_scale=0.5, residual=res.cuda(), out=out[:m])
+        ref = (ref + bias) * 0.5 + res.float()
+    else:
+        r = res.cuda()
+        ops.gemm(a.cuda(), w.cuda(), bias=bias.cuda(), residual=r, blend=r, alpha=0.3, out=out[:m])
+        ref = 0.3 * res.float() + 0.7 * (ref + bias + res.float())
+    close(out[:m], ref, dtype, scale=2.0)
+    assert (out[m:] == 7.0).all()
+    # strided operands (a column slice of a wider tensor, as the fused QK / context buffers are)
+    wide = torch.zeros(m, 2 * k, dtype=dtype, device="cuda")
+    wide[:, k:] = a.cuda()
+    close(ops.gemm(wide[:, k:], w.cuda()), a.float() @ w.float().T, dtype, scale=2.0)
+
+
 @pytest.mark.parametrize("n,rowvec", [(160, False), (128, False), (320, True)])
 def test_gemm_tall_short_k(ops, n, rowvec):
     """the model's tall, short-K linears (M ~ 1e5, K = 64): ragged last tile, FiLM row vector spanning tile boundaries,

@@ -104,4 +104,34 @@ __device__ __forceinline__ void glds16(const void* gsrc, char* lds_wave_base) {
 }
 __device__ __forceinline__ uint4 lds_read16(const char* smem, int off) { return *(const uint4*)(smem + off); }
 
+// ---- LDS access the compiler cannot see.  hipcc guards every LDS access that may alias an in-flight LDS-DMA with
+// `s_waitcnt vmcnt(0)`, which drains the prefetch ring before each tile and makes counted vmcnt(N) pipelines pointless.
+// These wrappers issue the ds instruction as opaque asm; the CALLER orders them: lds_wait<N>() (s_waitcnt lgkmcnt(N) +
+// sched_barrier, cdna guide rule 18) before the first use of a raw read, and the usual vmcnt/barrier protocol against
+// the DMA.  LDS instructions of one wave complete in order, so lds_wait<N> retires all but the N most recent.
+__device__ __forceinline__ unsigned lds_addr(const void* p) {
+  return (unsigned)(unsigned long)((__attribute__((address_space(3))) const char*)p);
+}
+typedef unsigned raw_u32x4_t __attribute__((ext_vector_type(4)));
+typedef unsigned raw_u32x2_t __attribute__((ext_vector_type(2)));
+typedef float raw_f32x4_t __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ raw_u32x4_t lds_read16_raw(unsigned addr) {
+  raw_u32x4_t v;
+  asm volatile("ds_read_b128 %0, %1" : "=v"(v) : "v"(addr));
+  return v;
+}
+__device__ __forceinline__ raw_u32x2_t lds_read8_raw(unsigned addr) {
+  raw_u32x2_t v;
+  asm volatile("ds_read_b64 %0, %1" : "=v"(v) : "v"(addr));
+  return v;
+}
+__device__ __forceinline__ void lds_write16_raw(unsigned addr, float a, float b, float c, float d) {
+  const raw_f32x4_t v = {a, b, c, d};
+  asm volatile("ds_write_b128 %0, %1" ::"v"(addr), "v"(v) : "memory");
+}
+template <int N> __device__ __forceinline__ void lds_wait() {
+  asm volatile("s_waitcnt lgkmcnt(%0)" ::"n"(N) : "memory");
+  __builtin_amdgcn_sched_barrier(0);
+}
+
 static inline int ceil_div(long a, long b) { return (int)((a + b - 1) / b); }

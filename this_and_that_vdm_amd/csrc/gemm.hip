@@ -311,19 +311,26 @@ void gemm_kernel(const GemmP p) {
   for (int j = 0; j < FN; ++j) b_lds_row[j] = wc * WTN + j * 32 + l31;
 
   constexpr int KS = BK / 16;                 // MFMA k sub-steps per tile (even)
-  auto read_frags = [&](const char* sa, int ks, uint4 (&af)[FM], uint4 (&bf)[FN]) {
-    const char* sb = sa + A_BYTES;
+  // Fragment reads are raw ds_read_b128 (common.h): with compiler-visible LDS loads hipcc puts `s_waitcnt vmcnt(0)` in
+  // front of the first read of every K step -- AFTER the next tile's DMA has been issued -- so load latency and MFMA time
+  // add up instead of overlapping (1.1-1.5 us per 64-deep step, measured).  The reads of one fragment set are retired
+  // by lds_wait<reads issued after them>() before the MFMAs that consume them.
+  constexpr int NF = FM + FN;                 // ds_read_b128 per fragment set
+  const unsigned lds_base = lds_addr(smem);
+  auto read_frags = [&](unsigned sa, int ks, raw_u32x4_t (&af)[FM], raw_u32x4_t (&bf)[FN]) {
+    const unsigned sb = sa + A_BYTES;
     const int chunk = ks * 2 + hi;
 #pragma unroll
-    for (int i = 0; i < FM; ++i) af[i] = lds_read16(sa, tile_off<CPR>(a_lds_row[i], chunk));
+    for (int i = 0; i < FM; ++i) af[i] = lds_read16_raw(sa + tile_off<CPR>(a_lds_row[i], chunk));
 #pragma unroll
-    for (int j = 0; j < FN; ++j) bf[j] = lds_read16(sb, tile_off<CPR>(b_lds_row[j], chunk));
+    for (int j = 0; j < FN; ++j) bf[j] = lds_read16_raw(sb + tile_off<CPR>(b_lds_row[j], chunk));
   };
-  auto mma = [&](const uint4 (&af)[FM], const uint4 (&bf)[FN]) {
+  auto mma = [&](const raw_u32x4_t (&af)[FM], const raw_u32x4_t (&bf)[FN]) {
 #pragma unroll
     for (int i = 0; i < FM; ++i)
 #pragma unroll
-      for (int j = 0; j < FN; ++j) acc[i][j] = Cvt<Tag>::mfma32(bf[j], af[i], acc[i][j]);
+      for (int j = 0; j < FN; ++j)
+        acc[i][j] = Cvt<Tag>::mfma32(make_uint4(bf[j].x, bf[j].y, bf[j].z, bf[j].w), make_uint4(af[i].x, af[i].y, af[i].z, af[i].w), acc[i][j]);
   };
 
   // residual operands of every (row, quad) this lane will finish (epilogue layout, see below): ONE batch of loads.
@@ -371,12 +378,18 @@ void gemm_kernel(const GemmP p) {
       if (kt == 0) TL(2);
 #endif
       if (kt + 1 < KT) stage((kt + 1) & 1);
-      const char* sa = smem + (kt & 1) * STAGE;
+      const unsigned sa = lds_base + (kt & 1) * STAGE;
+      raw_u32x4_t af[2][FM], bf[2][FN];         // fragment sets double-buffered: set ks+1 is read under the MFMAs of ks
+      read_frags(sa, 0, af[0], bf[0]);
 #pragma unroll
       for (int ks = 0; ks < KS; ++ks) {
-        uint4 af[FM], bf[FN];
-        read_frags(sa, ks, af, bf);
-        mma(af, bf);
+        if (ks + 1 < KS) {
+          read_frags(sa, ks + 1, af[(ks + 1) & 1], bf[(ks + 1) & 1]);
+          lds_wait<NF>();
+        } else {
+          lds_wait<0>();
+        }
+        mma(af[ks & 1], bf[ks & 1]);
       }
     }
   } else {
@@ -388,25 +401,30 @@ void gemm_kernel(const GemmP p) {
     wait_tiles<G>(min(KT - 1, NST - 2));      // tile 0 landed
     __builtin_amdgcn_s_barrier();
     asm volatile("" ::: "memory");
-    uint4 afA[FM], bfA[FN], afB[FM], bfB[FN];
-    read_frags(smem, 0, afA, bfA);
+    raw_u32x4_t afA[FM], bfA[FN], afB[FM], bfB[FN];
+    read_frags(lds_base, 0, afA, bfA);
     int slot = 0, fill = NST - 1;             // slot of tile kt ; slot the next staged tile goes to
     for (int kt = 0; kt < KT; ++kt) {
-      const char* sa = smem + slot * STAGE;
+      const unsigned sa = lds_base + slot * STAGE;
       const int nslot = slot + 1 == NST ? 0 : slot + 1;
 #pragma unroll
       for (int ks = 0; ks < KS; ks += 2) {
         read_frags(sa, ks + 1, afB, bfB);
+        lds_wait<NF>();                       // set A (issued before set B) has landed
         mma(afA, bfA);
         if (ks + 2 < KS) {
           read_frags(sa, ks + 2, afA, bfA);
+          lds_wait<NF>();                     // set B has landed
         } else if (kt + 1 < KT) {
           // tile kt+1 must have landed; tiles kt+2 .. min(KT-1, kt+NST-2) may stay in flight
           wait_tiles<G>(min(KT - 2 - kt, NST - 3));
           __builtin_amdgcn_s_barrier();       // all waves: tile kt+1 visible, tile kt-1's slot free
           asm volatile("" ::: "memory");
           if (kt + NST - 1 < KT) stage(fill);
-          read_frags(smem + nslot * STAGE, 0, afA, bfA);
+          read_frags(lds_base + nslot * STAGE, 0, afA, bfA);
+          lds_wait<NF>();
+        } else {
+          lds_wait<0>();
         }
         mma(afB, bfB);
       }
@@ -622,6 +640,167 @@ void gemm_kernel(const GemmP p) {
   }
 }
 
+// ---- (opt-in: tt_gemm_set_streaming_square / TT_GEMM_SQ320=1) square C = 320 linears of the finest UNet level (to_out /
+// to_q / proj_in / proj_out at 32x56 latents: ~60 launches per step, M = 50176).  Measured: 31 us against 36 us for the
+// tiled kernel in isolation, but 0.1-0.3 ms per step SLOWER inside the two-branch graph (one 160 KiB block per CU leaves
+// no room for the other branch's kernels), hence off by default.  The tiled kernel above needs 1.5 rounds of lock-stepped blocks for them and re-reads W from L2
+// for every tile (36-50 us against ~20 us for their 64-96 MB at HBM speed).  Here W never touches LDS: each of the 10
+// waves of a block keeps its 32 output columns x 320 K of W in registers (20 MFMA operands = 80 VGPRs) for the whole
+// launch, blocks are persistent over 32-row tiles of A, and LDS holds only a deep ring of A (and residual) tiles filled
+// by LDS-DMA, so the launch streams A / residual / out at HBM speed with several tiles in flight per CU.
+// Epilogue terms: bias, scale, residual, AlphaBlender with the residual as its source (the plain variant above).
+constexpr int SQ_K = 320, SQ_N = 320, SQ_ROWS = 32, SQ_WAVES = SQ_N / 32, SQ_NT = 64 * SQ_WAVES;
+constexpr int SQ_CPR = SQ_K / 8;                               // 16-byte chunks per tile row (40)
+constexpr int SQ_TILE_BYTES = SQ_ROWS * SQ_K * 2;              // 20 KiB: one A (or residual) tile
+constexpr int SQ_PASSES = SQ_ROWS * SQ_CPR / SQ_NT;            // DMA instructions per thread per tile (2)
+static_assert(SQ_ROWS * SQ_CPR % SQ_NT == 0 && SQ_CPR % 8 == 0, "sq320 staging");
+__device__ __forceinline__ int sq_swz(int row) { return (row >> 1) & 7; }     // 640-byte rows: see tile_swz
+__device__ __forceinline__ int sq_off(int row, int chunk) { return (row * SQ_CPR + (chunk ^ sq_swz(row))) << 4; }
+
+template <typename Tag, bool HAS_RES>
+__global__ __launch_bounds__(SQ_NT) void sq320_kernel(const GemmP p) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  constexpr int G = HAS_RES ? 2 * SQ_PASSES : SQ_PASSES;       // DMA instructions per thread per ring slot
+  constexpr int SLOT = HAS_RES ? 2 * SQ_TILE_BYTES : SQ_TILE_BYTES;
+  constexpr int NST = HAS_RES ? 3 : 5;                         // ring depth: 120 / 100 KiB + 40 KiB of strips
+  constexpr int KS = SQ_K / 16;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int l31 = lane & 31, hi = lane >> 5;
+  const int ntiles = (p.m + SQ_ROWS - 1) / SQ_ROWS;
+  const int my_tiles = blockIdx.x < ntiles ? (ntiles - 1 - (int)blockIdx.x) / (int)gridDim.x + 1 : 0;
+  const __amdgpu_buffer_rsrc_t ra = make_rsrc(p.a0, p.a0_bytes);
+  const __amdgpu_buffer_rsrc_t rr = make_rsrc(p.residual, p.res_bytes);
+  const __amdgpu_buffer_rsrc_t rw = make_rsrc(p.w, p.w_bytes);
+
+  // ---- W operands of this wave's 32 columns: lane (column l31, k-half hi) holds k = ks*16 + hi*8 .. +8
+  uint4 wf[KS];
+  {
+    const int voff = (int)(((long)(wid * 32 + l31) * p.ldw + hi * 8) * 2);
+#pragma unroll
+    for (int ks = 0; ks < KS; ++ks) {
+      const u32x4_t v = __builtin_amdgcn_raw_buffer_load_b128(rw, voff, ks * 32, 0);
+      wf[ks] = make_uint4(v.x, v.y, v.z, v.w);
+    }
+  }
+  const int qq = lane & 7, rr_ = lane >> 3;                    // epilogue layout: 8 quads per 32-column row, 8 rows per pass
+  const int gn = wid * 32 + qq * 4;
+  const float4 b4 = ld128f(make_rsrc(p.bias, p.bias_bytes), gn * 4);
+  const float alpha = p.blend ? p.alpha : 0.0f, one_m_alpha = 1.0f - alpha;
+  const __amdgpu_buffer_rsrc_t r_out = make_rsrc(p.out, p.out_bytes);
+
+  // per-thread source offsets inside a tile (the tile's first row is a scalar offset)
+  int voa[SQ_PASSES], vor[SQ_PASSES], vrow[SQ_PASSES];
+#pragma unroll
+  for (int i = 0; i < SQ_PASSES; ++i) {
+    const int c = i * SQ_NT + tid, row = c / SQ_CPR, ch = (c % SQ_CPR) ^ sq_swz(row);
+    vrow[i] = row;
+    voa[i] = (int)(((long)row * p.lda0 + ch * 8) * 2);
+    vor[i] = (int)(((long)row * p.ld_res + ch * 8) * 2);
+  }
+  auto stage = [&](int j, int slot) {        // j-th tile of this block; beyond the end it still issues G (dropped) loads
+    // straight-line on purpose: with a branch around the DMA hipcc loses count of the loads in flight and drains them
+    // (vmcnt(0)) before every tile.  Past the last tile every row fails the bounds test, so nothing is fetched.
+    const int m0 = ((int)blockIdx.x + j * (int)gridDim.x) * SQ_ROWS;
+    char* la = smem + slot * SLOT + wid * 1024;
+    const int soa = __builtin_amdgcn_readfirstlane((int)((long)m0 * p.lda0 * 2));
+    const int sor = __builtin_amdgcn_readfirstlane((int)((long)m0 * p.ld_res * 2));
+#pragma unroll
+    for (int i = 0; i < SQ_PASSES; ++i)
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(ra, (__attribute__((address_space(3))) void*)(la + i * (SQ_NT * 16)), 16,
+                                               m0 + vrow[i] < p.m ? voa[i] : kInv, soa, 0, 0);
+    if constexpr (HAS_RES) {
+#pragma unroll
+      for (int i = 0; i < SQ_PASSES; ++i)
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rr, (__attribute__((address_space(3))) void*)(la + SQ_TILE_BYTES + i * (SQ_NT * 16)), 16,
+                                                 m0 + vrow[i] < p.m ? vor[i] : kInv, sor, 0, 0);
+    }
+  };
+  const unsigned lds_base = lds_addr(smem);
+  const unsigned strip = lds_base + NST * SLOT + wid * 4096;    // 32 rows x 128 bytes (fp32 x 32 columns), swizzled
+  auto strip_off = [](int row, int quad) { return row * 128 + ((quad ^ (row & 7)) << 4); };
+
+  // one tile: `after` = VMEM instructions this thread issued after the DMA of tile j (all of them may stay in flight)
+  auto tile = [&](int j, int slot, int fill, auto after_tag) {
+    constexpr int AFTER = decltype(after_tag)::value;
+    wait_vmcnt<AFTER>();
+    __builtin_amdgcn_s_barrier();            // tile j visible to all waves; every wave is done with tile j-1's slot
+    asm volatile("" ::: "memory");
+    stage(j + NST - 1, fill);
+    const unsigned sa = lds_base + slot * SLOT;
+    f32x16_t acc;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+    // A fragments in batches of 2 (raw LDS reads, see lds_read16_raw): batch b+1 is in flight under batch b's MFMAs
+    constexpr int FB = 2, NB = KS / FB;
+    static_assert(KS % FB == 0, "fragment batches");
+    raw_u32x4_t af[2][FB];
+#pragma unroll
+    for (int f = 0; f < FB; ++f) af[0][f] = lds_read16_raw(sa + sq_off(l31, f * 2 + hi));
+#pragma unroll
+    for (int bt = 0; bt < NB; ++bt) {
+      if (bt + 1 < NB) {
+#pragma unroll
+        for (int f = 0; f < FB; ++f) af[(bt + 1) & 1][f] = lds_read16_raw(sa + sq_off(l31, ((bt + 1) * FB + f) * 2 + hi));
+        lds_wait<FB>();
+      } else {
+        lds_wait<0>();
+      }
+#pragma unroll
+      for (int f = 0; f < FB; ++f) {
+        const raw_u32x4_t a4 = af[bt & 1][f];
+        acc = Cvt<Tag>::mfma32(wf[bt * FB + f], make_uint4(a4.x, a4.y, a4.z, a4.w), acc);
+      }
+    }
+    // epilogue of the wave's 32 x 32 block: transpose through the strip, 4 passes of 8 rows x 64 bytes.
+    // The raw ds_write is invisible to hipcc's hazard recogniser: the MFMA results need their 18 wait states by hand.
+    __builtin_amdgcn_sched_barrier(0);
+    asm volatile("s_nop 15\n\ts_nop 15" ::: "memory");
+#pragma unroll
+    for (int g = 0; g < 4; ++g)
+      lds_write16_raw(strip + strip_off(l31, 2 * g + hi), acc[g * 4], acc[g * 4 + 1], acc[g * 4 + 2], acc[g * 4 + 3]);
+    const int m0 = ((int)blockIdx.x + j * (int)gridDim.x) * SQ_ROWS;
+    raw_u32x4_t tq[4];
+    raw_u32x2_t rq[4];
+#pragma unroll
+    for (int pass = 0; pass < 4; ++pass) {
+      const int r = pass * 8 + rr_;
+      tq[pass] = lds_read16_raw(strip + strip_off(r, qq));
+      rq[pass] = (raw_u32x2_t){0u, 0u};
+      if constexpr (HAS_RES) rq[pass] = lds_read8_raw(sa + SQ_TILE_BYTES + sq_off(r, gn >> 3) + (gn & 7) * 2);
+    }
+    lds_wait<0>();
+#pragma unroll
+    for (int pass = 0; pass < 4; ++pass) {
+      const int r = pass * 8 + rr_;
+      const float t4[4] = {__uint_as_float(tq[pass].x), __uint_as_float(tq[pass].y), __uint_as_float(tq[pass].z), __uint_as_float(tq[pass].w)};
+      float v[4], r4[4];
+      unpack4<Tag>(make_uint2(rq[pass].x, rq[pass].y), r4);
+      const float bb[4] = {b4.x, b4.y, b4.z, b4.w};
+#pragma unroll
+      for (int e = 0; e < 4; ++e) v[e] = alpha * r4[e] + one_m_alpha * ((t4[e] + bb[e]) * p.acc_scale + r4[e]);
+      const int gm = m0 + r;
+      st64(r_out, gm < p.m ? (int)(((long)gm * p.ldo + gn) * 2) : kInv, pack2<Tag>(v[0], v[1]), pack2<Tag>(v[2], v[3]));
+    }
+  };
+
+  // ---- ring: tiles 0 .. NST-2 in flight before the loop; iteration j waits for tile j and issues tile j+NST-1.
+  // VMEM instructions per iteration after its wait: G loads + 4 stores, hence the counts below.
+#pragma unroll
+  for (int s = 0; s < NST - 1; ++s) stage(s, s);
+  int slot = 0, fill = NST - 1;
+  auto advance = [&]() { slot = slot + 1 == NST ? 0 : slot + 1; fill = fill + 1 == NST ? 0 : fill + 1; };
+  int j = 0;
+  // first NST-1 iterations: fewer instructions separate a tile's DMA from its use
+  if (j < my_tiles) { tile(j, slot, fill, std::integral_constant<int, (NST - 2) * G>{}); advance(); ++j; }
+  if (j < my_tiles) { tile(j, slot, fill, std::integral_constant<int, (NST - 3 > 0 ? NST - 3 : 0) * G + (G + 4)>{}); advance(); ++j; }
+  if constexpr (NST > 3) {
+    if (j < my_tiles) { tile(j, slot, fill, std::integral_constant<int, (NST - 4 > 0 ? NST - 4 : 0) * G + 2 * (G + 4)>{}); advance(); ++j; }
+    if (j < my_tiles) { tile(j, slot, fill, std::integral_constant<int, (NST - 5 > 0 ? NST - 5 : 0) * G + 3 * (G + 4)>{}); advance(); ++j; }
+  }
+  for (; j < my_tiles; ++j) { tile(j, slot, fill, std::integral_constant<int, 4 + (NST - 2) * (G + 4)>{}); advance(); }
+}
+
 // split-K second pass: sum the fp32 slabs in a fixed order (bit-reproducible) and run the normal epilogue
 template <typename Tag>
 __global__ __launch_bounds__(256) void splitk_epilogue_kernel(const GemmP p) {
@@ -794,6 +973,31 @@ extern "C" int tt_gemm_set_tile_override(int32_t cfg) {
   return TT_OK;
 }
 
+static int g_sq320 = -1;
+extern "C" int tt_gemm_set_streaming_square(int32_t on) {
+  g_sq320 = on ? 1 : 0;
+  return TT_OK;
+}
+
+bool sq320_ok(const TtGemmArgs* a) {
+  if (g_sq320 < 0) { const char* e = getenv("TT_GEMM_SQ320"); g_sq320 = e ? atoi(e) : 0; }
+  return g_sq320 && forced_cfg() < 0 && a->mode == 0 && a->k1 == 0 && a->k0 == SQ_K && a->n == SQ_N && a->m >= 4096 &&
+         !a->geglu && !a->rowvec && !a->out_f32 && !a->out_col_hw &&
+         (!a->blend || (a->blend == a->residual && a->ld_blend == a->ld_res));
+}
+template <typename Tag, bool HAS_RES>
+void launch_sq320(const GemmP& p, hipStream_t st) {
+  constexpr size_t lds = (size_t)(HAS_RES ? 3 * 2 * SQ_TILE_BYTES : 5 * SQ_TILE_BYTES) + SQ_WAVES * 4096;
+  static_assert(lds <= 160 * 1024, "sq320 LDS");
+  static bool attr_done = false;
+  if (!attr_done) {
+    (void)hipFuncSetAttribute((const void*)sq320_kernel<Tag, HAS_RES>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    attr_done = true;
+  }
+  const int ntiles = (p.m + SQ_ROWS - 1) / SQ_ROWS;
+  hipLaunchKernelGGL((sq320_kernel<Tag, HAS_RES>), dim3(ntiles < 256 ? ntiles : 256), dim3(SQ_NT), lds, st, p);
+}
+
 static Plan plan_for(const TtGemmArgs* a) {
   const int taps = a->mode == 1 ? 9 : (a->mode == 2 ? 3 : 1);
   const bool allow = !a->geglu;
@@ -802,6 +1006,10 @@ static Plan plan_for(const TtGemmArgs* a) {
 
 extern "C" int tt_gemm_plan(const TtGemmArgs* a, int32_t cfg[7]) {
   if (!a || !cfg || a->m <= 0 || a->n <= 0) TT_FAIL(TT_EINVAL, "tt_gemm_plan: bad arguments");
+  if (sq320_ok(a)) {          // the streaming kernel for the 320 x 320 linears: 32-row tiles, ring depth 3 (5 without residual)
+    cfg[0] = SQ_ROWS; cfg[1] = SQ_N; cfg[2] = SQ_K; cfg[3] = a->residual ? 3 : 5; cfg[4] = 1; cfg[5] = SQ_WAVES; cfg[6] = 1;
+    return TT_OK;
+  }
   Plan pl = plan_for(a);
   if (pl.splitk > 1 && (!a->ws || (size_t)a->ws_bytes < (size_t)pl.splitk * a->m * a->n * sizeof(float) ||
                         (long)pl.splitk * a->m * a->n * 4 >= (1L << 31)))
@@ -867,6 +1075,14 @@ extern "C" int tt_gemm(const TtGemmArgs* a, tt_stream_t stream) {
     p.out_bytes = (unsigned)outb; p.res_bytes = (unsigned)resb; p.blend_bytes = (unsigned)blb;
     p.bias_bytes = p.bias ? (unsigned)p.n * 4u : 0u; p.rowvec_bytes = (unsigned)rvb; p.ws_bytes = 0;
   }
+  hipStream_t st = (hipStream_t)stream;
+  if (sq320_ok(a)) {
+    p.splitk = 1; p.ws = nullptr; p.ws_bytes = 0;
+    if (a->dtype == TT_BF16) { if (p.residual) launch_sq320<bf16_tag, true>(p, st); else launch_sq320<bf16_tag, false>(p, st); }
+    else { if (p.residual) launch_sq320<f16_tag, true>(p, st); else launch_sq320<f16_tag, false>(p, st); }
+    TT_CHECK_LAUNCH("tt_gemm");
+    return TT_OK;
+  }
   Plan pl = plan_for(a);
   if (pl.splitk > 1 && (!a->ws || (size_t)a->ws_bytes < (size_t)pl.splitk * a->m * a->n * sizeof(float)))
     pl = Plan{make_plan(a->m, a->n, 0, false, !(a->residual || a->blend || a->rowvec)).cfg, 1};            // no workspace: un-split plan (still correct)
@@ -875,7 +1091,6 @@ extern "C" int tt_gemm(const TtGemmArgs* a, tt_stream_t stream) {
   p.splitk = pl.splitk;
   p.ws = (float*)a->ws;
   p.ws_bytes = pl.splitk > 1 ? (unsigned)((long)pl.splitk * a->m * a->n * 4) : 0u;
-  hipStream_t st = (hipStream_t)stream;
   if (a->dtype == TT_BF16) launch<bf16_tag>(p, pl.cfg, st); else launch<f16_tag>(p, pl.cfg, st);
   TT_CHECK_LAUNCH("tt_gemm");
   return TT_OK;

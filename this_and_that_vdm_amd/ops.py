@@ -123,7 +123,11 @@ def gemm(a0: torch.Tensor, w: torch.Tensor, *, a1: Optional[torch.Tensor] = None
         lib.tt_gemm_plan(C.byref(g), cfg)
         taps = 9 if mode == 1 else (3 if mode == 2 else 1)
         tag = "bf16_tag" if g.dtype == TT_BF16 else "f16_tag"
-        _prof_end(ev, f"gemm_kernel<{tag}, {', '.join(str(v) for v in cfg[:6])}, {mode}>", 2.0 * g.m * n * taps * (g.k0 + g.k1),
+        if cfg[0] == 32 and cfg[1] == 320:          # the opt-in streaming kernel for the 320 x 320 linears
+            kname = f"sq320_kernel<{tag}, {'true' if residual is not None else 'false'}>"
+        else:
+            kname = f"gemm_kernel<{tag}, {', '.join(str(v) for v in cfg[:6])}, {mode}>"
+        _prof_end(ev, kname, 2.0 * g.m * n * taps * (g.k0 + g.k1),
                   shape=(mode, g.m, n, taps * (g.k0 + g.k1), int(geglu), int(residual is not None)))
     return out
 
