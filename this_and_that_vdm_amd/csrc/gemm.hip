@@ -920,6 +920,18 @@ Plan make_plan(int m, int n, long ktot, bool allow_split, bool wide_ok = true) {
   const int fs = forced_split();
   if (fs >= 1) { pl.splitk = allow_split ? fs : 1; return pl; }
   const long kt = (ktot + 63) / 64;
+  static int deep = -1;
+  if (deep < 0) { const char* e = getenv("TT_GEMM_DEEP"); deep = e ? atoi(e) : 1; }
+  if (deep && f < 0 && b128 <= 256 && ktot > 0) {
+    // at most one 128x128 tile per CU: LDS is free for a 4-deep ring (prefetch distance 3), which beats two resident
+    // blocks with a double buffer once the loads really overlap the MFMAs; K is split only as far as whole CUs are idle
+    pl.cfg = 25;
+    long s = allow_split ? 256 / b128 : 1;
+    if (s > kt / 8) s = kt / 8;
+    if (s > 16) s = 16;
+    pl.splitk = s >= 2 ? (int)s : 1;
+    return pl;
+  }
   if (allow_split && f < 0 && b128 < 384 && kt >= 40) {
     long s = (512 + b128 - 1) / b128;
     if (s > kt / 8) s = kt / 8;
