@@ -364,12 +364,12 @@ void gemm_kernel(const GemmP p) {
         }
     }
   };
-  preload_residual();
-  TL(1);
-
   if constexpr (NST == 2) {
-    // plain double buffer: wait tile kt, barrier, issue tile kt+1, compute tile kt
+    // plain double buffer: wait tile kt, barrier, issue tile kt+1, compute tile kt.  The first tile is requested before
+    // the residual batch (whose address arithmetic costs ~2 us); the first wait covers both.
     stage(0);
+    preload_residual();
+    TL(1);
     for (int kt = 0; kt < KT; ++kt) {
       wait_vmcnt<0>();
       __builtin_amdgcn_s_barrier();
@@ -393,6 +393,8 @@ void gemm_kernel(const GemmP p) {
       }
     }
   } else {
+    preload_residual();                       // before the ring fill: the counted waits below assume the DMAs come last
+    TL(1);
     // software pipeline: fragments double-buffered in registers; the wait+barrier for tile kt+1 sits BEFORE the last
     // MFMA group of tile kt, so the first fragments of tile kt+1 are read (and tile kt+NST-1 is issued) under MFMAs.
 #pragma unroll
