@@ -46,17 +46,28 @@ __global__ __launch_bounds__(256) void attn_kernel(const AttnP p) {
   const int tid = threadIdx.x, lane = tid & 63;
   const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int l31 = lane & 31, hi = lane >> 5;
-  const int qblk = blockIdx.x, head = blockIdx.y, seq = blockIdx.z;
+  const int head = blockIdx.y, seq = blockIdx.z;
   const char* zero = (const char*)tt_zero_page;
 
-  // ---- which keys does this sequence see
-  int kbase, vbase, ntiles;
-  if (MASK == 0) { kbase = seq * p.k_seq_stride; vbase = seq * p.v_seq_stride; ntiles = (p.lk + KB - 1) / KB; }
-  else if (MASK == 1) { const int b = p.batch0 + seq / p.frames; kbase = b * p.k_seq_stride; vbase = b * p.v_seq_stride; ntiles = (p.lk + KB - 1) / KB; }
-  else { kbase = 0; vbase = 0; ntiles = (p.ctx_batches * p.k_seq_stride + KB - 1) / KB; }
+  // ---- which queries does this block own, which keys do they see.
+  // Temporal cross-attention (mask 2, reference quirk Q3): query q of sequence (b, frame) attends context (b*lq + q) % CB.
+  // Queries of one residue class q % CB share their context, so a block takes QB queries of ONE class (row stride CB):
+  // the context is block-uniform and the block stages only that context's keys (2 tiles of 64 for 78 tokens, instead of
+  // 3 masked tiles over both contexts with a division per score).
+  const int qstride = MASK == 2 ? p.ctx_batches : 1;
+  const int qcls = MASK == 2 ? (int)blockIdx.x % qstride : 0;
+  const int qblk = MASK == 2 ? (int)blockIdx.x / qstride : (int)blockIdx.x;
+  int kbase, vbase;
+  if (MASK == 0) { kbase = seq * p.k_seq_stride; vbase = seq * p.v_seq_stride; }
+  else {
+    const int b = p.batch0 + seq / p.frames;
+    const int ctx = MASK == 1 ? b : (int)(((long)b * p.lq + qcls) % p.ctx_batches);
+    kbase = ctx * p.k_seq_stride; vbase = ctx * p.v_seq_stride;
+  }
+  const int ntiles = (p.lk + KB - 1) / KB;
 
   // ---- Q^T fragments straight from global: lane (query l31) holds d = ds*16 + hi*8 .. +8
-  const int qrow = qblk * QB + wid * 32 + l31;
+  const int qrow = (qblk * QB + wid * 32 + l31) * qstride + qcls;
   const bool qok = qrow < p.lq;
   uint4 qf[DS];
   {
@@ -64,9 +75,6 @@ __global__ __launch_bounds__(256) void attn_kernel(const AttnP p) {
 #pragma unroll
     for (int ds = 0; ds < DS; ++ds) qf[ds] = qok ? *(const uint4*)(qp + (ds * 16 + hi * 8) * 2) : make_uint4(0, 0, 0, 0);
   }
-  // temporal-cross pairing (reference quirk Q3): the context this query may look at
-  int my_ctx = 0;
-  if (MASK == 2) my_ctx = (int)((((long)(p.batch0 + seq / p.frames)) * p.lq + (qok ? qrow : 0)) % p.ctx_batches);
 
   // staging by buffer_load ... lds: per-lane 32-bit byte offsets computed once, the tile position is a scalar offset,
   // out-of-range rows/columns land beyond num_records and read as zeros (same scheme as gemm.hip).
@@ -144,17 +152,14 @@ __global__ __launch_bounds__(256) void attn_kernel(const AttnP p) {
     // ---- mask + online softmax (lane: one query, keys j0 + kb*32 + hi*16 + r).  Raw scores stay unscaled: the
     // 1/sqrt(d)*log2(e) factor c is folded into the exponent, p = exp2(s*c - m*c), one FMA per score.
     const int j0 = t * KB;
-    const bool need_mask = MASK == 2 || j0 + KB > p.lk;         // uniform: interior tiles of masks 0/1 skip the compares
+    const bool need_mask = j0 + KB > p.lk;                      // uniform: interior tiles skip the compares
     if (need_mask) {
 #pragma unroll
       for (int kb = 0; kb < 2; ++kb)
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
           const int j = j0 + kb * 32 + hi * 16 + r;
-          bool ok;
-          if (MASK == 2) { const int cb = j / p.k_seq_stride; ok = (j - cb * p.k_seq_stride) < p.lk && cb == my_ctx; }
-          else ok = j < p.lk;
-          if (!ok) s[kb][r] = -INFINITY;
+          if (j >= p.lk) s[kb][r] = -INFINITY;
         }
     }
     float mx = s[0][0];
@@ -220,7 +225,9 @@ void launch_attn_m(const AttnP& p, hipStream_t st) {
     (void)hipFuncSetAttribute((const void*)attn_kernel<Tag, D, MASK>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     attr_done = true;
   }
-  const dim3 grid((p.lq + QB - 1) / QB, p.heads, p.nseq);
+  // mask 2: one block per (query residue class, QB queries of that class)
+  const int cls = MASK == 2 ? p.ctx_batches : 1;
+  const dim3 grid(cls * ((((p.lq + cls - 1) / cls) + QB - 1) / QB), p.heads, p.nseq);
   hipLaunchKernelGGL((attn_kernel<Tag, D, MASK>), grid, dim3(256), lds, st, p);
 }
 template <typename Tag, int D>
