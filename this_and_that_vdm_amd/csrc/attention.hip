@@ -201,19 +201,31 @@ __global__ __launch_bounds__(256) void attn_kernel(const AttnP p) {
       }
     }
   }
-  // ---- finalize: lane holds query l31, d = db*32 + 8g + 4hi + {0..3}
+  // ---- finalize: lane holds query l31, d = db*32 + 8g + 4hi + {0..3}.  Stored directly an instruction would write 16
+  // bytes to each of 32 rows; instead the wave's 32 x D outputs go through a private LDS strip (the K/V ring is free
+  // now) and leave as full rows: 8 (D = 64) or 16 lanes cover one row's D*2 contiguous bytes.
   float l_tot = l_run + __shfl_xor(l_run, 32);
   const float inv = l_tot > 0.f ? 1.0f / l_tot : 0.f;
-  if (qok) {
-    char* op = p.out + (((long)seq * p.lq + qrow) * p.ldo + head * D) * 2;
+  __syncthreads();                                     // every wave is done with the K / V tiles
+  constexpr int ROWB_O = D * 2, CPR_O = ROWB_O / 16;   // output row bytes per head, 16-byte chunks per row
+  char* strip = smem + wid * (32 * ROWB_O);
+  static_assert(4 * 32 * ROWB_O <= 2 * STAGE, "output strips do not fit the K/V ring");
 #pragma unroll
-    for (int db = 0; db < DB; ++db)
+  for (int db = 0; db < DB; ++db)
 #pragma unroll
-      for (int g = 0; g < 4; ++g) {
-        const int d = db * 32 + 8 * g + 4 * hi;
-        *(uint2*)(op + d * 2) = make_uint2(pack2<Tag>(o[db][g * 4] * inv, o[db][g * 4 + 1] * inv),
-                                           pack2<Tag>(o[db][g * 4 + 2] * inv, o[db][g * 4 + 3] * inv));
-      }
+    for (int g = 0; g < 4; ++g) {
+      const int chunk = db * 4 + g;                    // 16-byte chunk of d = chunk*8 .. +8; this lane owns half hi
+      *(uint2*)(strip + l31 * ROWB_O + ((chunk ^ (l31 & (CPR_O - 1))) << 4) + hi * 8) =
+          make_uint2(pack2<Tag>(o[db][g * 4] * inv, o[db][g * 4 + 1] * inv), pack2<Tag>(o[db][g * 4 + 2] * inv, o[db][g * 4 + 3] * inv));
+    }
+  constexpr int RPP = 64 / CPR_O;                      // rows per pass
+  const int oc = lane % CPR_O, orow = lane / CPR_O;
+#pragma unroll
+  for (int pass = 0; pass < 32 / RPP; ++pass) {
+    const int r = pass * RPP + orow;
+    const uint4 v = *(const uint4*)(strip + r * ROWB_O + ((oc ^ (r & (CPR_O - 1))) << 4));
+    const int qr = (qblk * QB + wid * 32 + r) * qstride + qcls;
+    if (qr < p.lq) *(uint4*)(p.out + (((long)seq * p.lq + qr) * p.ldo + head * D) * 2 + oc * 16) = v;
   }
 }
 
@@ -354,7 +366,7 @@ extern "C" int tt_attention(const TtAttnArgs* a, tt_stream_t stream) {
   if (a->head_dim != 64 && a->head_dim != 128) TT_FAIL(TT_EUNSUPPORTED, "tt_attention: head_dim %d (64 or 128)", a->head_dim);
   if (a->nseq <= 0 || a->lq <= 0 || a->heads <= 0 || a->lk <= 0) TT_FAIL(TT_EINVAL, "tt_attention: empty problem");
   if (a->mask < 0 || a->mask > 2) TT_FAIL(TT_EINVAL, "tt_attention: mask %d", a->mask);
-  if ((a->ldq & 7) || (a->ldk & 7) || (a->ldvt & 7) || (a->ldo & 3) || (a->v_seq_stride & 7))
+  if ((a->ldq & 7) || (a->ldk & 7) || (a->ldvt & 7) || (a->ldo & 7) || (a->v_seq_stride & 7))
     TT_FAIL(TT_EINVAL, "tt_attention: strides must keep 16-byte chunks aligned");
   if (a->mask != 0 && (a->frames <= 0 || a->ctx_batches <= 0 || a->nseq % a->frames)) TT_FAIL(TT_EINVAL, "tt_attention: frames/ctx");
   if (a->mask != 0 && (a->batch0 < 0 || a->batch0 + a->nseq / a->frames > a->ctx_batches)) TT_FAIL(TT_EINVAL, "tt_attention: batch0 + batches exceeds ctx_batches");
