@@ -391,6 +391,30 @@ def test_gemm_tall_short_k(ops, n, rowvec):
     assert (out[m:] == 7.0).all()
 
 
+@pytest.mark.parametrize("m,n,k,cfg", [(12544, 640, 640, -1), (3136, 1280, 1280, -1), (12544, 2560, 320, -1), (50176, 320, 320, -1),
+                                       (3136, 1280, 640, 1), (1500, 640, 1280, 2), (8192, 1024, 512, 21), (4096, 640, 512, 23)])
+def test_gemm_is_repeatable_under_load(ops, m, n, k, cfg):
+    """the K loop reads LDS with instructions the compiler cannot see and orders them against the LDS-DMA by counted
+    waits and barriers only: a misplaced wait would show up as run-to-run differences.  40 launches back to back
+    (other launches in flight, operands rotating) must be bit-identical to the first."""
+    from this_and_that_vdm_amd import _lib
+    lib = _lib.load()
+    dtype = torch.bfloat16
+    a = [rnd(m, k, dtype=dtype, seed=10 + i).cuda() for i in range(2)]
+    w = rnd(n, k, dtype=dtype, seed=2, scale=k ** -0.5).cuda()
+    res = rnd(m, n, dtype=dtype, seed=5).cuda()
+    try:
+        lib.tt_gemm_set_tile_override(cfg)
+        first = [ops.gemm(a[i], w, residual=res).clone() for i in range(2)]
+        close(first[0], a[0].float().cpu() @ w.float().cpu().T + res.float().cpu(), dtype, scale=2.0)
+        outs = [ops.gemm(a[i % 2], w, residual=res) for i in range(40)]
+        torch.cuda.synchronize()
+        for i, o in enumerate(outs):
+            assert torch.equal(o, first[i % 2]), f"launch {i} differs"
+    finally:
+        lib.tt_gemm_set_tile_override(-1)
+
+
 @pytest.mark.parametrize("dtype", DTYPES)
 def test_gemm_split_k_is_used_and_exact(ops, dtype):
     """few tiles + long K -> the planner asks for workspace and splits K; fixed-order slab reduction."""
