@@ -79,8 +79,17 @@ class EulerDiscreteScheduler:
         return prev
 
 
+def controlnet_keep(num_steps, control_guidance_start=0.0, control_guidance_end=1.0):
+    """svd/pipeline_stable_video_diffusion_controlnet.py:611-617 for a single ControlNetModel: step i keeps the
+    ControlNet (1.0) unless i/n < start or (i+1)/n > end (0.0)."""
+    s = control_guidance_start[0] if isinstance(control_guidance_start, (list, tuple)) else control_guidance_start
+    e = control_guidance_end[0] if isinstance(control_guidance_end, (list, tuple)) else control_guidance_end
+    return [1.0 - float(i / num_steps < s or (i + 1) / num_steps > e) for i in range(num_steps)]
+
+
 def denoise_loop(unet, controlnet, scheduler, latents, image_latents, encoder_hidden_states, added_time_ids,
-                 controlnet_cond, guidance_scale, num_inference_steps=25, conditioning_scale=1.0, return_all=False):
+                 controlnet_cond, guidance_scale, num_inference_steps=25, conditioning_scale=1.0, return_all=False,
+                 control_guidance_start=0.0, control_guidance_end=1.0):
     """Loop body of svd/pipeline_stable_video_diffusion_controlnet.py:624-720 (VL twin
     svd/pipeline_stable_video_diffusion.py:528-562 when ``controlnet is None``).
 
@@ -89,8 +98,9 @@ def denoise_loop(unet, controlnet, scheduler, latents, image_latents, encoder_hi
     latents, loop-invariant -- quirk Q6/Q12), guidance_scale [1,F,1,1,1].
     """
     scheduler.set_timesteps(num_inference_steps)
+    keep = controlnet_keep(len(scheduler.timesteps), control_guidance_start, control_guidance_end)
     trace = []
-    for t in scheduler.timesteps:
+    for i, t in enumerate(scheduler.timesteps):
         x = torch.cat([latents] * 2)
         x = scheduler.scale_model_input(x, t)
         x = torch.cat([x, image_latents], dim=2)
@@ -98,7 +108,7 @@ def denoise_loop(unet, controlnet, scheduler, latents, image_latents, encoder_hi
         if controlnet is not None:
             cc = torch.cat([controlnet_cond, controlnet_cond])
             down, mid = controlnet(x, t, encoder_hidden_states, added_time_ids, controlnet_cond=cc,
-                                   conditioning_scale=conditioning_scale, guess_mode=False)
+                                   conditioning_scale=conditioning_scale * keep[i], guess_mode=False)   # :639-645
         eps = unet(x, t, encoder_hidden_states, added_time_ids,
                    down_block_additional_residuals=down, mid_block_additional_residual=mid)
         u, c = eps.chunk(2)

@@ -89,3 +89,44 @@ def test_fused_residual_add_equals_public_api():
     s = err_stats(fused, api)
     print("fused step vs public-API step:", s)
     assert s["rel_l2"] <= 2e-3, s
+
+
+@torch.no_grad()
+def test_control_guidance_window_matches_oracle_loop():
+    """controlnet_keep (reference :611-617,639-645): steps outside [start, end] run with the residuals scaled by 0.
+    The product replays a UNet-only graph for those steps; the oracle multiplies the scale like the reference."""
+    if not torch.cuda.is_available():
+        pytest.skip("needs a GPU")
+    from oracle.scheduler import EulerDiscreteScheduler as OSched, controlnet_keep, denoise_loop
+    from this_and_that_vdm_amd.svd.denoise import DenoiseLoop
+    from this_and_that_vdm_amd.svd.scheduling_euler_discrete import EulerDiscreteScheduler
+    p_unet, p_cn, o_unet, o_cn = build_pair("tiny_vgl", torch.float16, "cuda:0", True)
+    inp = _inputs()
+    steps = 4
+    keep = controlnet_keep(steps, 0.25, 0.75)
+    assert keep == [0.0, 1.0, 1.0, 0.0]
+    ref = denoise_loop(o_unet, o_cn, OSched(), inp["latents"], inp["image_latents"], inp["encoder_hidden_states"],
+                       inp["added_time_ids"], inp["gesture_latents"], inp["guidance_scale"], num_inference_steps=steps,
+                       control_guidance_start=0.25, control_guidance_end=0.75)
+    sched = EulerDiscreteScheduler()
+    sched.set_timesteps(steps)
+    kw = dict(latents=inp["latents"], image_latents=inp["image_latents"], encoder_hidden_states=inp["encoder_hidden_states"],
+              added_time_ids=inp["added_time_ids"], guidance_scale=inp["guidance_scale"], sigmas=sched.sigmas,
+              timesteps=sched.timesteps, controlnet_cond=inp["gesture_latents"])
+    outs = {}
+    for graph in (True, False):
+        outs[graph] = DenoiseLoop(p_unet, p_cn, use_graph=graph).begin(**kw, controlnet_keep=keep).run().clone()
+        torch.cuda.synchronize()
+    assert torch.equal(outs[True], outs[False]), "two-graph replay must equal eager launches"
+    s = err_stats(outs[True], ref)
+    print("windowed loop vs oracle:", s)
+    assert s["rel_l2"] <= 1e-2 and s["cos"] >= 0.9999, s
+    full = DenoiseLoop(p_unet, p_cn, use_graph=True).begin(**kw).run().clone()
+    assert not torch.equal(full, outs[True])
+    # keep == 0 everywhere is the VL loop, bit for bit
+    none = DenoiseLoop(p_unet, p_cn, use_graph=True).begin(**kw, controlnet_keep=[0.0] * steps).run().clone()
+    kw_vl = dict(kw, controlnet_cond=None)
+    vl = DenoiseLoop(p_unet, None, use_graph=True).begin(**kw_vl).run().clone()
+    assert torch.equal(none, vl)
+    with pytest.raises(ValueError):
+        DenoiseLoop(p_unet, p_cn).begin(**kw, controlnet_keep=[1.0])

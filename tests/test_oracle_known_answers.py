@@ -89,3 +89,28 @@ def test_denoise_loop_runs_and_is_deterministic():
     b = denoise_loop(unet, cn, EulerDiscreteScheduler(), *args, num_inference_steps=3)
     assert a.shape == (1, 2, 4, 8, 8) and torch.isfinite(a).all()
     torch.testing.assert_close(a, b, rtol=0, atol=0)
+
+
+@torch.no_grad()
+def test_controlnet_keep_windows():
+    """svd/pipeline_stable_video_diffusion_controlnet.py:611-617 evaluated by hand: 25 steps, window [0.2, 0.6] keeps
+    steps 5..14 (i/25 >= 0.2 and (i+1)/25 <= 0.6); the defaults keep everything; a loop whose window excludes every step
+    is the ControlNet-free loop."""
+    from oracle.scheduler import controlnet_keep
+    assert controlnet_keep(25) == [1.0] * 25
+    assert controlnet_keep(25, 0.2, 0.6) == [0.0] * 5 + [1.0] * 10 + [0.0] * 10
+    assert controlnet_keep(4, [0.25], [0.75]) == [0.0, 1.0, 1.0, 0.0]
+    assert controlnet_keep(3, 0.0, 0.5) == [1.0, 0.0, 0.0]
+    kw = dict(block_out_channels=(32, 64, 64, 64), num_attention_heads=(1, 1, 2, 2), cross_attention_dim=32)
+    unet = UNetSpatioTemporalConditionModel(num_frames=2, **kw).eval()
+    cn = ControlNetModel(**kw).eval()
+    fill_parameters_(unet, "unet.")
+    fill_parameters_(cn, "controlnet.")
+    inp = synthetic_inputs(2, 2, 8, 8, ctx_tokens=3, ctx_dim=32)
+    args = (inp["latents"], inp["image_latents"], inp["encoder_hidden_states"], inp["added_time_ids"],
+            inp["gesture_latents"], inp["guidance_scale"])
+    full = denoise_loop(unet, cn, EulerDiscreteScheduler(), *args, num_inference_steps=2)
+    off = denoise_loop(unet, cn, EulerDiscreteScheduler(), *args, num_inference_steps=2, control_guidance_start=0.9)
+    vl = denoise_loop(unet, None, EulerDiscreteScheduler(), *args, num_inference_steps=2)
+    torch.testing.assert_close(off, vl, rtol=0, atol=0)
+    assert not torch.equal(full, vl)

@@ -57,6 +57,16 @@ def test_vgl_pipeline_latent_output_matches_oracle_loop(parts):
     s = err_stats(lat, ref)
     print("pipeline vs oracle loop:", s)
     assert s["rel_l2"] <= 1e-2, s
+    # control-guidance window (reference :611-617): 3 steps, end = 0.5 -> the ControlNet acts on step 0 only
+    win = pipe(image.cuda(), cond, p_cn, prompt=ids.cuda(), use_text=True, text_encoder=txt, height=64, width=128, num_frames=4,
+               num_inference_steps=3, fps=7, motion_bucket_id=200, noise_aug_strength=0.0, latents=lat0.clone(),
+               output_type="latent", guess_mode=False, generator=torch.Generator().manual_seed(1),
+               control_guidance_start=0.0, control_guidance_end=0.5).frames
+    ref_w = denoise_loop(o_unet, o_cn, sched, lat0 * sched.init_noise_sigma, il, ehs, torch.tensor([[6.0, 200.0, 0.0]] * 2), ges,
+                         torch.linspace(1, 3, 4).view(1, 4, 1, 1, 1), num_inference_steps=3, control_guidance_end=0.5)
+    s = err_stats(win, ref_w)
+    print("windowed pipeline vs oracle loop:", s)
+    assert s["rel_l2"] <= 1e-2 and not torch.equal(win, lat), s
 
 
 @torch.no_grad()
@@ -84,3 +94,6 @@ def test_argument_errors(parts):
         pipe(image.cuda(), cond, p_cn, height=60, width=128, num_frames=4, guess_mode=False)
     with pytest.raises(NotImplementedError):
         pipe(image.cuda(), cond, p_cn, height=64, width=128, num_frames=4, use_instructpix2pix=True, guess_mode=False)
+    with pytest.raises(ValueError, match="window"):
+        pipe(image.cuda(), cond, p_cn, height=64, width=128, num_frames=4, guess_mode=False, control_guidance_start=0.8,
+             control_guidance_end=0.2)

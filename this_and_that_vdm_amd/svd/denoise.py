@@ -9,10 +9,12 @@ Hoisted out of the loop (step-invariant; the reference recomputes them every ste
 context K/V of all 46 cross-attention layers, frame-position embeddings, and the gesture-map latents (the
 pipeline VAE-encodes them once instead of 25 times, reference :652).
 Step-dependent scalars (sigma_i, sigma_{i+1}, t_i) live in a 3-float device buffer that is refreshed by one
-tiny copy before each replay, so a single captured graph serves all steps.  No host sync inside the loop."""
+tiny copy before each replay, so a single captured graph serves all steps.  No host sync inside the loop.
+Control-guidance windows (reference :611-617,639-645): a step whose ``controlnet_keep`` is 0 multiplies every residual
+by 0, i.e. it is exactly the UNet-only step -- such steps replay a second graph that does not launch GestureNet at all."""
 from __future__ import annotations
 
-from typing import Optional
+from typing import Optional, Sequence
 
 import torch
 
@@ -29,16 +31,19 @@ class DenoiseLoop:
         self.overlap_branches = True        # False: same launches, one stream (used when timing kernels one by one)
         self._streams = {}
         self._graph = None
+        self._graph_off = None              # the UNet-only step for controlnet_keep[i] == 0
         self._key = None
         self._static = {}
 
     # ---- request set-up (everything step-invariant)
     def begin(self, latents: torch.Tensor, image_latents: torch.Tensor, encoder_hidden_states: torch.Tensor,
               added_time_ids: torch.Tensor, guidance_scale: Optional[torch.Tensor], sigmas: torch.Tensor,
-              timesteps: torch.Tensor, controlnet_cond: Optional[torch.Tensor] = None, conditioning_scale: float = 1.0):
+              timesteps: torch.Tensor, controlnet_cond: Optional[torch.Tensor] = None, conditioning_scale: float = 1.0,
+              controlnet_keep: Optional[Sequence[float]] = None):
         """latents [1,F,4,h,w] (already scaled by init_noise_sigma); image_latents [B,F,4,h,w]; encoder_hidden_states
         [B,S,D]; added_time_ids [B,3]; guidance_scale [1,F,1,1,1] or None (no CFG: B == 1); sigmas [steps+1],
-        timesteps [steps]; controlnet_cond [F,4,h,w] gesture latents (same for both CFG halves, reference :660)."""
+        timesteps [steps]; controlnet_cond [F,4,h,w] gesture latents (same for both CFG halves, reference :660); controlnet_keep: one 0.0/1.0 per step
+        (reference :611-617), None = keep everywhere."""
         dev = self.unet.device
         self.unet.prepare()
         b = image_latents.shape[0]
@@ -49,7 +54,7 @@ class DenoiseLoop:
         key = (b, f, h, w, dtype, self.controlnet is not None, tuple(encoder_hidden_states.shape), len(timesteps),
                guidance_scale is not None)
         if key != self._key:                    # new shapes: new static buffers, new graph
-            self._graph, self._key, self._static = None, key, {}
+            self._graph, self._graph_off, self._key, self._static = None, None, key, {}
         self.geom, self.dtype = Geom(b, f, h, w), dtype
         f32 = lambda t: t.to(device=dev, dtype=torch.float32).contiguous()
         sig = f32(sigmas)
@@ -78,6 +83,9 @@ class DenoiseLoop:
             if self._static.setdefault("cn_scales", self.cn_scales) != self.cn_scales:
                 self._graph = None              # the scale is a launch argument baked into the graph
                 self._static["cn_scales"] = self.cn_scales
+        self.keep = [1.0] * self.num_steps if controlnet_keep is None else [float(v) for v in controlnet_keep]
+        if len(self.keep) != self.num_steps or any(v not in (0.0, 1.0) for v in self.keep):
+            raise ValueError("controlnet_keep needs one 0.0/1.0 entry per step")
         self.step_index = 0
         return self
 
@@ -88,19 +96,19 @@ class DenoiseLoop:
             return cur
         self._static[name] = value.clone()          # never alias the caller's tensor: latents are updated in place
         if cur is not None:
-            self._graph = None
+            self._graph = self._graph_off = None
         return self._static[name]
 
     # ---- one step's launches (captured once)
-    def _launch_step(self):
+    def _launch_step(self, use_cn: bool = True):
         """One step as concurrent branches (fork/join with events; captured as parallel hipGraph branches).
         GestureNet's encoder+mid is independent of the UNet's until the zero-convs, so the two run side by side: the
         latency-bound small kernels and the tails of one branch fill the idle CUs of the other (49.8 -> 44.4 ms/step).
         With ``split_cfg`` the uncond / cond halves (which never interact inside the networks) become branches too."""
         g = self.geom
-        cn = self.controlnet
+        cn = self.controlnet if use_cn else None
         cpad = cn._cin_pad if cn is not None else self.unet._cin_pad
-        x_tok = ops.prep_model_input(self.latents, self.image_latents, self.cond, self.cur, 0, g.batch, g.frames, g.h, g.w,
+        x_tok = ops.prep_model_input(self.latents, self.image_latents, self.cond if use_cn else None, self.cur, 0, g.batch, g.frames, g.h, g.w,
                                      cpad, self.dtype)
         t = self.cur[2:3]
         x_unet = x_tok if cpad == self.unet._cin_pad else x_tok[:, :self.unet._cin_pad]
@@ -155,27 +163,32 @@ class DenoiseLoop:
         if self.step_index >= self.num_steps:
             raise RuntimeError("denoise loop already finished; call begin() for a new request")
         self.cur.copy_(self.table[self.step_index])
+        use_cn = self.controlnet is not None and self.keep[self.step_index] != 0.0
         if not self.use_graph:
-            self._launch_step()
-        else:
+            self._launch_step(use_cn)
+        elif use_cn or self.controlnet is None:
             if self._graph is None:
-                self._capture()
+                self._graph = self._capture(self.controlnet is not None)
             self._graph.replay()
+        else:
+            if self._graph_off is None:
+                self._graph_off = self._capture(False)
+            self._graph_off.replay()
         self.step_index += 1
 
-    def _capture(self):
+    def _capture(self, use_cn: bool):
         # warm-up on a side stream (allocator + lazily built caches), restoring the latents afterwards
         keep = self.latents.clone()
         s = torch.cuda.Stream()
         s.wait_stream(torch.cuda.current_stream())
         with torch.cuda.stream(s):
-            self._launch_step()
+            self._launch_step(use_cn)
         torch.cuda.current_stream().wait_stream(s)
         graph = torch.cuda.CUDAGraph()
         with torch.cuda.graph(graph):
-            self._launch_step()
+            self._launch_step(use_cn)
         self.latents.copy_(keep)
-        self._graph = graph
+        return graph
 
     def run(self, steps: Optional[int] = None) -> torch.Tensor:
         n = self.num_steps - self.step_index if steps is None else steps

@@ -137,7 +137,8 @@ class _SVDPipelineCore(PipelineBase):
     def _generate(self, image, condition_img, controlnet, prompt, use_text, text_encoder, height, width, num_frames,
                   num_inference_steps, min_guidance_scale, max_guidance_scale, fps, motion_bucket_id, noise_aug_strength,
                   decode_chunk_size, num_videos_per_prompt, generator, latents, output_type, callback_on_step_end,
-                  callback_on_step_end_tensor_inputs, return_dict, controlnet_conditioning_scale=1.0):
+                  callback_on_step_end_tensor_inputs, return_dict, controlnet_conditioning_scale=1.0,
+                  control_guidance_start=0.0, control_guidance_end=1.0):
         height = height or self.unet.config.sample_size * self.vae_scale_factor
         width = width or self.unet.config.sample_size * self.vae_scale_factor
         num_frames = num_frames if num_frames is not None else self.unet.config.num_frames
@@ -176,13 +177,18 @@ class _SVDPipelineCore(PipelineBase):
         self._num_timesteps = len(timesteps)
         scale = controlnet_conditioning_scale[0] if isinstance(controlnet_conditioning_scale, list) else controlnet_conditioning_scale
 
+        # which steps keep the ControlNet (reference :611-617): 0.0 outside [start, end], else 1.0
+        n = len(timesteps)
+        keep = [1.0 - float(i / n < control_guidance_start or (i + 1) / n > control_guidance_end) for i in range(n)]
+
         key = controlnet is not None
         loop = self._loops.get(key)
         if loop is None or loop.controlnet is not controlnet:
             loop = self._loops[key] = DenoiseLoop(self.unet, controlnet, use_graph=True)
         loop.begin(latents=latents, image_latents=image_latents, encoder_hidden_states=ehs, added_time_ids=added_time_ids,
                    guidance_scale=guidance if do_cfg else None, sigmas=self.scheduler.sigmas, timesteps=timesteps,
-                   controlnet_cond=gesture_latents, conditioning_scale=float(scale))
+                   controlnet_cond=gesture_latents, conditioning_scale=float(scale),
+                   controlnet_keep=keep if controlnet is not None else None)
         with self.progress_bar(total=num_inference_steps) as bar:
             for i, t in enumerate(timesteps):
                 loop.step()
@@ -244,8 +250,16 @@ class StableVideoDiffusionControlNetPipeline(_SVDPipelineCore):
             raise NotImplementedError("use_instructpix2pix=True (3-way CFG) is not built; the shipped config sets it False")
         if not isinstance(controlnet, ControlNetModel):
             raise TypeError("controlnet must be a ControlNetModel")
-        if (control_guidance_start, control_guidance_end) not in ((0.0, 1.0), ([0.0], [1.0])):
-            raise NotImplementedError("control_guidance_start/end other than the defaults 0.0/1.0 (controlnet_keep == 1 for all steps)")
+        # the reference wraps both in a one-element list (:485-489), so only scalars work there; a one-element list
+        # is accepted here as well
+        if isinstance(control_guidance_start, (list, tuple)) or isinstance(control_guidance_end, (list, tuple)):
+            if not (isinstance(control_guidance_start, (list, tuple)) and isinstance(control_guidance_end, (list, tuple))
+                    and len(control_guidance_start) == len(control_guidance_end) == 1):
+                raise ValueError("control_guidance_start/end: one value each (a single ControlNetModel)")
+            control_guidance_start, control_guidance_end = control_guidance_start[0], control_guidance_end[0]
+        if control_guidance_start >= control_guidance_end or control_guidance_start < 0.0 or control_guidance_end > 1.0:
+            raise ValueError(f"control guidance window [{control_guidance_start}, {control_guidance_end}] must satisfy "
+                             "0 <= start < end <= 1")
         if guess_mode and max_guidance_scale > 1.0 and not getattr(self, "_warned_guess", False):
             # reference: guess_mode + CFG zeroes the uncond residuals (:676-681); inference always passes False
             raise NotImplementedError("guess_mode=True with CFG is not built (test_code/inference.py passes guess_mode=False)")
@@ -253,4 +267,4 @@ class StableVideoDiffusionControlNetPipeline(_SVDPipelineCore):
                               num_inference_steps, min_guidance_scale, max_guidance_scale, fps, motion_bucket_id,
                               noise_aug_strength, decode_chunk_size, num_videos_per_prompt, generator, latents, output_type,
                               callback_on_step_end, callback_on_step_end_tensor_inputs, return_dict,
-                              controlnet_conditioning_scale)
+                              controlnet_conditioning_scale, float(control_guidance_start), float(control_guidance_end))
