@@ -170,6 +170,8 @@ int tt_timestep_embedding(const float* t, int32_t rows, int32_t dim, float* out,
  *   latents/image_latents/cond are fp32 NCHW-per-frame as the pipeline holds them.
  * tt_cfg_euler_step: eps[b,f,p,0:4] fp32 token-major (conv_out) ->
  *   v = u + g_f*(c-u);  x0 = v*(-s/sqrt(s^2+1)) + x/(s^2+1);  x += (x-x0)/s*(s_next-s)   (in place, fp32)
+ * tt_cfg3_euler_step: the use_instructpix2pix variant (:698-702), eps batch of 3 in the reference's order
+ *   (first-frame e1, cond c, uncond u):  v = u + g_f*(c-u) + image_guidance_scale*(c-e1), then the same Euler update.
  * sigma scalars live on the device (sigmas[step], sigmas[step+1]) so a captured graph can be replayed
  * for every step.
  * ---------------------------------------------------------------------------------------------- */
@@ -178,6 +180,8 @@ int tt_prep_model_input(const float* latents, const float* image_latents, const 
                         void* x, int32_t dtype, tt_stream_t stream);
 int tt_cfg_euler_step(const float* eps, int32_t ld_eps, float* latents, const float* guidance, const float* sigmas,
                       int32_t step, int32_t batch, int32_t frames, int32_t h, int32_t w, tt_stream_t stream);
+int tt_cfg3_euler_step(const float* eps, int32_t ld_eps, float* latents, const float* guidance, float image_guidance_scale,
+                       const float* sigmas, int32_t step, int32_t frames, int32_t h, int32_t w, tt_stream_t stream);
 
 /* layout plumbing at the drop-in boundary: NCHW (any float dtype code below) <-> token-major.
  * src_kind/dst_kind: 0 = dtype (bf16/f16), 1 = fp32. */

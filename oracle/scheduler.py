@@ -89,30 +89,37 @@ def controlnet_keep(num_steps, control_guidance_start=0.0, control_guidance_end=
 
 def denoise_loop(unet, controlnet, scheduler, latents, image_latents, encoder_hidden_states, added_time_ids,
                  controlnet_cond, guidance_scale, num_inference_steps=25, conditioning_scale=1.0, return_all=False,
-                 control_guidance_start=0.0, control_guidance_end=1.0):
+                 control_guidance_start=0.0, control_guidance_end=1.0, use_instructpix2pix=False, image_guidance_scale=7.5):
     """Loop body of svd/pipeline_stable_video_diffusion_controlnet.py:624-720 (VL twin
     svd/pipeline_stable_video_diffusion.py:528-562 when ``controlnet is None``).
 
     latents [1,F,4,h,w] (already * init_noise_sigma), image_latents [2,F,4,h,w] (uncond zeros first),
     encoder_hidden_states [2,S,1024], added_time_ids [2,3], controlnet_cond [F,4,h,w] (pre-encoded gesture
     latents, loop-invariant -- quirk Q6/Q12), guidance_scale [1,F,1,1,1].
+    ``use_instructpix2pix`` (:627-628,656-657,698-702): the constants carry a batch of 3 in the reference's order
+    (context: cond, 0, 0 :182-184; image latents: cond, cond, 0 :208-210) and the guidance combines three predictions.
     """
+    nb = 3 if use_instructpix2pix else 2
     scheduler.set_timesteps(num_inference_steps)
     keep = controlnet_keep(len(scheduler.timesteps), control_guidance_start, control_guidance_end)
     trace = []
     for i, t in enumerate(scheduler.timesteps):
-        x = torch.cat([latents] * 2)
+        x = torch.cat([latents] * nb)
         x = scheduler.scale_model_input(x, t)
         x = torch.cat([x, image_latents], dim=2)
         down = mid = None
         if controlnet is not None:
-            cc = torch.cat([controlnet_cond, controlnet_cond])
+            cc = torch.cat([controlnet_cond] * nb)
             down, mid = controlnet(x, t, encoder_hidden_states, added_time_ids, controlnet_cond=cc,
                                    conditioning_scale=conditioning_scale * keep[i], guess_mode=False)   # :639-645
         eps = unet(x, t, encoder_hidden_states, added_time_ids,
                    down_block_additional_residuals=down, mid_block_additional_residual=mid)
-        u, c = eps.chunk(2)
-        eps = u + guidance_scale * (c - u)
+        if use_instructpix2pix:
+            e1, c, u = eps.chunk(3)                 # "1st_frame", cond, uncond (:699)
+            eps = u + guidance_scale * (c - u) + image_guidance_scale * (c - e1)
+        else:
+            u, c = eps.chunk(2)
+            eps = u + guidance_scale * (c - u)
         latents = scheduler.step(eps, t, latents)
         if return_all:
             trace.append(latents.clone())

@@ -130,3 +130,80 @@ def test_control_guidance_window_matches_oracle_loop():
     assert torch.equal(none, vl)
     with pytest.raises(ValueError):
         DenoiseLoop(p_unet, p_cn).begin(**kw, controlnet_keep=[1.0])
+
+
+@torch.no_grad()
+def test_instructpix2pix_loop_matches_oracle_loop():
+    """use_instructpix2pix (reference :182-184,208-210,627-628,698-702): CFG batch of 3 = (context+image, image only,
+    nothing); eps = uncond + g_f (cond - uncond) + image_guidance_scale (cond - first)."""
+    if not torch.cuda.is_available():
+        pytest.skip("needs a GPU")
+    from oracle.scheduler import EulerDiscreteScheduler as OSched, denoise_loop
+    from this_and_that_vdm_amd.svd.denoise import DenoiseLoop
+    from this_and_that_vdm_amd.svd.scheduling_euler_discrete import EulerDiscreteScheduler
+    p_unet, p_cn, o_unet, o_cn = build_pair("tiny_vgl", torch.float16, "cuda:0", True)
+    inp = _inputs()
+    img, ctx = inp["image_latents"][1:], inp["encoder_hidden_states"][1:]
+    il3 = torch.cat([img, img, torch.zeros_like(img)])
+    ehs3 = torch.cat([ctx, torch.zeros_like(ctx), torch.zeros_like(ctx)])
+    ids3 = inp["added_time_ids"][:1].repeat(3, 1)
+    steps, igs = 3, 1.5
+    ref = denoise_loop(o_unet, o_cn, OSched(), inp["latents"], il3, ehs3, ids3, inp["gesture_latents"], inp["guidance_scale"],
+                       num_inference_steps=steps, use_instructpix2pix=True, image_guidance_scale=igs)
+    sched = EulerDiscreteScheduler()
+    sched.set_timesteps(steps)
+    kw = dict(latents=inp["latents"], image_latents=il3, encoder_hidden_states=ehs3, added_time_ids=ids3,
+              guidance_scale=inp["guidance_scale"], sigmas=sched.sigmas, timesteps=sched.timesteps,
+              controlnet_cond=inp["gesture_latents"], image_guidance_scale=igs)
+    outs = {}
+    for graph in (True, False):
+        outs[graph] = DenoiseLoop(p_unet, p_cn, use_graph=graph).begin(**kw).run().clone()
+        torch.cuda.synchronize()
+    assert torch.equal(outs[True], outs[False])
+    s = err_stats(outs[True], ref)
+    print("instructpix2pix loop vs oracle:", s)
+    assert s["rel_l2"] <= 1e-2 and s["cos"] >= 0.9999, s
+    split = DenoiseLoop(p_unet, p_cn, use_graph=True, split_cfg=True).begin(**kw).run().clone()
+    assert torch.equal(split, outs[True]), "three concurrent CFG branches must reproduce the joint launch"
+    other = DenoiseLoop(p_unet, p_cn, use_graph=True).begin(**dict(kw, image_guidance_scale=0.0)).run().clone()
+    assert not torch.equal(other, outs[True])          # the image scale is live (and re-captures the graph)
+    with pytest.raises(ValueError):
+        DenoiseLoop(p_unet, p_cn).begin(**dict(kw, image_guidance_scale=None))
+
+
+@torch.no_grad()
+def test_guess_mode_without_cfg_uses_logspace_scales():
+    """guess_mode without CFG (batch 1): residual i is scaled by logspace(-1, 0, 13)[i] * conditioning_scale
+    (svd/temporal_controlnet.py:626-630).  One fused step vs the oracle's two forward() calls + scheduler."""
+    if not torch.cuda.is_available():
+        pytest.skip("needs a GPU")
+    from oracle.scheduler import EulerDiscreteScheduler as OSched
+    from this_and_that_vdm_amd.svd.denoise import DenoiseLoop
+    from this_and_that_vdm_amd.svd.scheduling_euler_discrete import EulerDiscreteScheduler
+    p_unet, p_cn, o_unet, o_cn = build_pair("tiny_vgl", torch.float16, "cuda:0", True)
+    inp = _inputs()
+    il, ehs, ids = inp["image_latents"][1:], inp["encoder_hidden_states"][1:], inp["added_time_ids"][:1]
+    sched = EulerDiscreteScheduler()
+    sched.set_timesteps(3)
+    kw = dict(latents=inp["latents"], image_latents=il, encoder_hidden_states=ehs, added_time_ids=ids, guidance_scale=None,
+              sigmas=sched.sigmas, timesteps=sched.timesteps, controlnet_cond=inp["gesture_latents"], conditioning_scale=0.7)
+    loop = DenoiseLoop(p_unet, p_cn, use_graph=True).begin(**kw, guess_mode=True)
+    loop.step()
+    got = loop.result().clone()
+    plain = DenoiseLoop(p_unet, p_cn, use_graph=True).begin(**kw)
+    plain.step()
+    assert not torch.equal(got, plain.result())
+    osch = OSched()
+    osch.set_timesteps(3)
+    t = osch.timesteps[0]
+    x = torch.cat([osch.scale_model_input(inp["latents"], t), il], dim=2)
+    down, mid = o_cn(x, t, ehs, ids, controlnet_cond=inp["gesture_latents"], conditioning_scale=0.7, guess_mode=True)
+    eps = o_unet(x, t, ehs, ids, down_block_additional_residuals=down, mid_block_additional_residual=mid)
+    ref = osch.step(eps, t, inp["latents"])
+    s = err_stats(got, ref)
+    print("guess-mode step vs oracle:", s)
+    assert s["rel_l2"] <= 1e-2, s
+    with pytest.raises(NotImplementedError):
+        DenoiseLoop(p_unet, p_cn).begin(**dict(kw, image_latents=inp["image_latents"], encoder_hidden_states=inp["encoder_hidden_states"],
+                                               added_time_ids=inp["added_time_ids"], guidance_scale=inp["guidance_scale"]),
+                                        guess_mode=True)

@@ -278,6 +278,23 @@ def test_denoise_glue_matches_oracle_scheduler(ops, dtype):
     lat_d = lat.clone().cuda()
     ops.cfg_euler_step(eps_tok, lat_d, g.cuda(), s.sigmas.cuda(), step, 2, f, h, w)
     torch.testing.assert_close(lat_d.cpu(), ref, rtol=1e-5, atol=1e-3)
+    # use_instructpix2pix: batch of 3 = (first-frame, cond, uncond), reference :698-702
+    img3 = rnd(3, f, 4, h, w, dtype=torch.float32, seed=5)
+    x3 = ops.prep_model_input(lat.cuda(), img3.cuda(), cond.cuda(), s.sigmas.cuda(), step, 3, f, h, w, 64, dtype)
+    got3 = x3.float().cpu().view(3, f, h, w, 64)
+    s._step_index = step
+    ref3 = torch.cat([s.scale_model_input(torch.cat([lat] * 3), t), img3, torch.cat([cond] * 3).view(3, f, 4, h, w)], dim=2)
+    close(got3[..., :12].permute(0, 1, 4, 2, 3), ref3, dtype)
+    eps3 = rnd(3, f, 4, h, w, dtype=torch.float32, seed=6)
+    e1, c3, u3 = eps3.chunk(3)
+    s._step_index = step
+    ref = s.step(u3 + g.view(1, f, 1, 1, 1) * (c3 - u3) + 7.5 * (c3 - e1), t, lat)
+    lat_d = lat.clone().cuda()
+    ops.cfg_euler_step(eps3.permute(0, 1, 3, 4, 2).reshape(-1, 4).contiguous().cuda(), lat_d, g.cuda(), s.sigmas.cuda(), step, 3,
+                       f, h, w, image_guidance_scale=7.5)
+    torch.testing.assert_close(lat_d.cpu(), ref, rtol=1e-5, atol=1e-3)
+    with pytest.raises(ValueError):
+        ops.cfg_euler_step(eps_tok, lat_d, g.cuda(), s.sigmas.cuda(), step, 3, f, h, w)
 
 
 @pytest.mark.parametrize("dtype", DTYPES)

@@ -114,3 +114,31 @@ def test_controlnet_keep_windows():
     vl = denoise_loop(unet, None, EulerDiscreteScheduler(), *args, num_inference_steps=2)
     torch.testing.assert_close(off, vl, rtol=0, atol=0)
     assert not torch.equal(full, vl)
+
+
+@torch.no_grad()
+def test_instructpix2pix_guidance_order():
+    """svd/pipeline_stable_video_diffusion_controlnet.py:627-628,698-702 with a stand-in UNet that returns the image-latent
+    channels of its input: the three predictions are then the three image-latent rows, in the reference's order
+    (first-frame, cond, uncond), and one Euler step has a closed form."""
+    f, h, w = 2, 4, 4
+    g = torch.Generator().manual_seed(0)
+    lat = torch.randn(1, f, 4, h, w, generator=g) * 700.0
+    il3 = torch.randn(3, f, 4, h, w, generator=g)
+    gs = torch.linspace(1.0, 3.0, f).view(1, f, 1, 1, 1)
+    seen = []
+
+    def fake_unet(x, t, ehs, ids, **kw):
+        seen.append(tuple(x.shape))
+        return x[:, :, 4:8]
+
+    sched = EulerDiscreteScheduler()
+    out = denoise_loop(fake_unet, None, sched, lat, il3, torch.zeros(3, 1, 8), torch.zeros(3, 3), None, gs,
+                       num_inference_steps=1, use_instructpix2pix=True, image_guidance_scale=7.5)
+    assert seen == [(3, f, 8, h, w)]
+    e1, c, u = il3[0:1], il3[1:2], il3[2:3]
+    v = u + gs * (c - u) + 7.5 * (c - e1)
+    s0 = float(sched.sigmas[0])
+    x0 = v * (-s0 / (s0 ** 2 + 1) ** 0.5) + lat / (s0 ** 2 + 1)
+    want = lat + (lat - x0) / s0 * (0.0 - s0)
+    torch.testing.assert_close(out, want, rtol=1e-5, atol=1e-4)

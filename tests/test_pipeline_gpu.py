@@ -70,6 +70,37 @@ def test_vgl_pipeline_latent_output_matches_oracle_loop(parts):
 
 
 @torch.no_grad()
+def test_vgl_pipeline_instructpix2pix_matches_oracle_loop(parts):
+    """use_instructpix2pix=True through the drop-in __call__: constants in the reference's 3-way order, oracle loop beside."""
+    from oracle.scheduler import EulerDiscreteScheduler as OSched, denoise_loop
+    from this_and_that_vdm_amd.svd import EulerDiscreteScheduler, StableVideoDiffusionControlNetPipeline
+    p_unet, p_cn, o_unet, o_cn, vae, clip, txt = parts
+    pipe = StableVideoDiffusionControlNetPipeline.from_pretrained(None, vae=vae, image_encoder=clip, unet=p_unet,
+                                                                  scheduler=EulerDiscreteScheduler())
+    pipe.set_progress_bar_config(disable=True)
+    image, cond, ids = _request()
+    lat0 = torch.randn(1, 4, 4, 8, 16, generator=torch.Generator().manual_seed(5))
+    lat = pipe(image.cuda(), cond, p_cn, prompt=ids.cuda(), use_text=True, text_encoder=txt, height=64, width=128, num_frames=4,
+               num_inference_steps=3, fps=7, motion_bucket_id=200, noise_aug_strength=0.0, latents=lat0.clone(),
+               output_type="latent", guess_mode=False, use_instructpix2pix=True, image_guidance_scale=1.5).frames
+    ehs = pipe.encode_clip(image.cuda(), ids.cuda(), True, txt, "cuda", 1, True, True).float().cpu()
+    assert ehs.shape == (3, 5, 64) and float(ehs[1:].abs().max()) == 0.0 and float(ehs[0].abs().max()) > 0.0
+    img = pipe.image_processor.preprocess(image, 64, 128)
+    il = pipe._encode_vae_image(img.cuda().half(), "cuda", 1, True, True).float().cpu()
+    assert il.shape[0] == 3 and torch.equal(il[0], il[1]) and float(il[2].abs().max()) == 0.0
+    il = il.unsqueeze(1).repeat(1, 4, 1, 1, 1)
+    ges = vae.encode(torch.from_numpy(cond).cuda().half()).latent_dist.mode().float().cpu()
+    sched = OSched()
+    sched.set_timesteps(3)
+    ref = denoise_loop(o_unet, o_cn, sched, lat0 * sched.init_noise_sigma, il, ehs, torch.tensor([[6.0, 200.0, 0.0]] * 3), ges,
+                       torch.linspace(1, 3, 4).view(1, 4, 1, 1, 1), num_inference_steps=3, use_instructpix2pix=True,
+                       image_guidance_scale=1.5)
+    s = err_stats(lat, ref)
+    print("instructpix2pix pipeline vs oracle loop:", s)
+    assert s["rel_l2"] <= 1e-2, s
+
+
+@torch.no_grad()
 def test_vl_pipeline_decodes_frames(parts):
     from this_and_that_vdm_amd.svd import StableVideoDiffusionPipeline
     p_unet, _, _, _, vae, clip, _ = parts
@@ -92,8 +123,8 @@ def test_argument_errors(parts):
     image, cond, _ = _request()
     with pytest.raises(ValueError, match="divisible by 8"):
         pipe(image.cuda(), cond, p_cn, height=60, width=128, num_frames=4, guess_mode=False)
-    with pytest.raises(NotImplementedError):
-        pipe(image.cuda(), cond, p_cn, height=64, width=128, num_frames=4, use_instructpix2pix=True, guess_mode=False)
+    with pytest.raises(NotImplementedError, match="guess_mode"):
+        pipe(image.cuda(), cond, p_cn, height=64, width=128, num_frames=4, guess_mode=True)
     with pytest.raises(ValueError, match="window"):
         pipe(image.cuda(), cond, p_cn, height=64, width=128, num_frames=4, guess_mode=False, control_guidance_start=0.8,
              control_guidance_end=0.2)

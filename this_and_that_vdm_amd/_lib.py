@@ -62,6 +62,7 @@ SIGNATURES = {
     "tt_timestep_embedding": (C.c_int, [_vp, _i32, _i32, _vp, _i64, _vp]),
     "tt_prep_model_input": (C.c_int, [_vp, _vp, _vp, _vp, _i32, _i32, _i32, _i32, _i32, _i32, _vp, _i32, _vp]),
     "tt_cfg_euler_step": (C.c_int, [_vp, _i32, _vp, _vp, _vp, _i32, _i32, _i32, _i32, _i32, _vp]),
+    "tt_cfg3_euler_step": (C.c_int, [_vp, _i32, _vp, _vp, C.c_float, _vp, _i32, _i32, _i32, _i32, _vp]),
     "tt_nchw_to_tokens": (C.c_int, [_vp, _i32, _i32, _i32, _i32, _vp, _i64, _i32, _vp]),
     "tt_tokens_to_nchw": (C.c_int, [_vp, _i32, _i64, _i32, _i32, _i32, _vp, _i32, _i32, _vp]),
     "tt_add_scaled": (C.c_int, [_vp, _vp, _f32, _vp, _i64, _i32, _vp]),

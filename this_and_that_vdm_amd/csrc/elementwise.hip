@@ -88,7 +88,7 @@ __global__ void prep_input_kernel(const float* lat, const float* img, const floa
 }
 
 __global__ void cfg_euler_kernel(const float* eps, int ld_eps, float* lat, const float* guidance, const float* sigmas,
-                                 int step, int batch, int frames, int hw) {
+                                 int step, int batch, int frames, int hw, float image_guidance) {
   const long total = (long)frames * hw;
   const float sg = sigmas[step], sn = sigmas[step + 1];
   const float c_out = -sg / sqrtf(sg * sg + 1.0f), c_skip = 1.0f / (sg * sg + 1.0f);
@@ -99,7 +99,12 @@ __global__ void cfg_euler_kernel(const float* eps, int ld_eps, float* lat, const
 #pragma unroll
     for (int c = 0; c < 4; ++c) {
       float v;
-      if (batch >= 2) {
+      if (batch == 3) {           // InstructPix2Pix order (reference :698-702): first-frame, cond, uncond
+        const float e1 = eps[((long)f * hw + p) * ld_eps + c];
+        const float cd = eps[(((long)frames + f) * hw + p) * ld_eps + c];
+        const float u = eps[(((long)2 * frames + f) * hw + p) * ld_eps + c];
+        v = u + g * (cd - u) + image_guidance * (cd - e1);
+      } else if (batch == 2) {
         const float u = eps[((long)f * hw + p) * ld_eps + c];
         const float cd = eps[(((long)frames + f) * hw + p) * ld_eps + c];
         v = u + g * (cd - u);
@@ -220,8 +225,19 @@ extern "C" int tt_cfg_euler_step(const float* eps, int32_t ld_eps, float* latent
   if (batch < 1 || batch > 2 || frames <= 0 || ld_eps < 4 || step < 0) TT_FAIL(TT_EINVAL, "tt_cfg_euler_step: batch must be 1 (no CFG) or 2 (uncond, cond)");
   const long total = (long)frames * h * w;
   long blocks = (total + 255) / 256; if (blocks > 2048) blocks = 2048;
-  hipLaunchKernelGGL(cfg_euler_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, eps, ld_eps, latents, guidance, sigmas, step, batch, frames, h * w);
+  hipLaunchKernelGGL(cfg_euler_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, eps, ld_eps, latents, guidance, sigmas, step, batch, frames, h * w, 0.0f);
   TT_CHECK_LAUNCH("tt_cfg_euler_step");
+  return TT_OK;
+}
+
+extern "C" int tt_cfg3_euler_step(const float* eps, int32_t ld_eps, float* latents, const float* guidance, float image_guidance_scale,
+                                  const float* sigmas, int32_t step, int32_t frames, int32_t h, int32_t w, tt_stream_t stream) {
+  if (!eps || !latents || !sigmas || !guidance) TT_FAIL(TT_EINVAL, "tt_cfg3_euler_step: null operand");
+  if (frames <= 0 || h <= 0 || w <= 0 || ld_eps < 4 || step < 0) TT_FAIL(TT_EINVAL, "tt_cfg3_euler_step: bad shape");
+  const long total = (long)frames * h * w;
+  long blocks = (total + 255) / 256; if (blocks > 2048) blocks = 2048;
+  hipLaunchKernelGGL(cfg_euler_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, eps, ld_eps, latents, guidance, sigmas, step, 3, frames, h * w, image_guidance_scale);
+  TT_CHECK_LAUNCH("tt_cfg3_euler_step");
   return TT_OK;
 }
 

@@ -227,8 +227,15 @@ def prep_model_input(latents, image_latents, cond, sigmas, step, batch, frames, 
     return x
 
 
-def cfg_euler_step(eps, latents, guidance, sigmas, step, batch, frames, h, w):
+def cfg_euler_step(eps, latents, guidance, sigmas, step, batch, frames, h, w, image_guidance_scale=None):
+    """batch 1 (no CFG), 2 (uncond, cond) or 3 (use_instructpix2pix: first-frame, cond, uncond + image_guidance_scale)."""
     lib = _lib.load()
+    if batch == 3:
+        if image_guidance_scale is None or guidance is None:
+            raise ValueError("a CFG batch of 3 needs guidance and image_guidance_scale")
+        check(lib.tt_cfg3_euler_step(_p(eps), eps.stride(0), _p(latents), _p(guidance), float(image_guidance_scale), _p(sigmas),
+                                     step, frames, h, w, _stream()), "tt_cfg3_euler_step")
+        return latents
     check(lib.tt_cfg_euler_step(_p(eps), eps.stride(0), _p(latents), _p(guidance), _p(sigmas), step, batch, frames, h, w,
                                 _stream()), "tt_cfg_euler_step")
     return latents

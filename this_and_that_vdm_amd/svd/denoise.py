@@ -39,20 +39,27 @@ class DenoiseLoop:
     def begin(self, latents: torch.Tensor, image_latents: torch.Tensor, encoder_hidden_states: torch.Tensor,
               added_time_ids: torch.Tensor, guidance_scale: Optional[torch.Tensor], sigmas: torch.Tensor,
               timesteps: torch.Tensor, controlnet_cond: Optional[torch.Tensor] = None, conditioning_scale: float = 1.0,
-              controlnet_keep: Optional[Sequence[float]] = None):
+              controlnet_keep: Optional[Sequence[float]] = None, image_guidance_scale: Optional[float] = None,
+              guess_mode: bool = False):
         """latents [1,F,4,h,w] (already scaled by init_noise_sigma); image_latents [B,F,4,h,w]; encoder_hidden_states
         [B,S,D]; added_time_ids [B,3]; guidance_scale [1,F,1,1,1] or None (no CFG: B == 1); sigmas [steps+1],
         timesteps [steps]; controlnet_cond [F,4,h,w] gesture latents (same for both CFG halves, reference :660); controlnet_keep: one 0.0/1.0 per step
-        (reference :611-617), None = keep everywhere."""
+        (reference :611-617), None = keep everywhere.  B == 3 is the use_instructpix2pix batch (first-frame, cond, uncond; reference
+        :182-184,208-210,698-702) and needs image_guidance_scale.  guess_mode: the 13 residual scales become
+        logspace(-1, 0, 13) * conditioning_scale (temporal_controlnet.py:626-630); only without CFG -- the reference's
+        guess-mode + CFG branch (:676-681) concatenates zeros onto an already CFG-sized residual batch and cannot run."""
         dev = self.unet.device
         self.unet.prepare()
         b = image_latents.shape[0]
         _, f, _, h, w = latents.shape
-        if b not in (1, 2):
-            raise NotImplementedError("CFG batch of 1 or 2 (use_instructpix2pix triples it; not built)")
+        if b not in (1, 2, 3):
+            raise ValueError("CFG batch must be 1 (no CFG), 2 (uncond, cond) or 3 (use_instructpix2pix)")
+        if b == 3 and (image_guidance_scale is None or guidance_scale is None):
+            raise ValueError("a CFG batch of 3 (use_instructpix2pix) needs guidance_scale and image_guidance_scale")
+        self.image_guidance_scale = float(image_guidance_scale) if b == 3 else None
         dtype = self.unet._run_dtype()
         key = (b, f, h, w, dtype, self.controlnet is not None, tuple(encoder_hidden_states.shape), len(timesteps),
-               guidance_scale is not None)
+               guidance_scale is not None, self.image_guidance_scale)          # the image scale is baked into the graph
         if key != self._key:                    # new shapes: new static buffers, new graph
             self._graph, self._graph_off, self._key, self._static = None, None, key, {}
         self.geom, self.dtype = Geom(b, f, h, w), dtype
@@ -71,6 +78,8 @@ class DenoiseLoop:
         self.ctx_unet = (self._static_set("k_unet", k), self._static_set("vt_unet", vt), s, sp)
         self.cond = None
         if self.controlnet is not None:
+            if guess_mode and b > 1:
+                raise NotImplementedError("guess_mode with CFG (the reference's branch :676-681 cannot run either)")
             if controlnet_cond is None:
                 raise ValueError("controlnet_cond (VAE-encoded gesture latents) is required with a ControlNet")
             self.controlnet.prepare()
@@ -79,7 +88,7 @@ class DenoiseLoop:
             self.cond = self._static_set("cond", f32(controlnet_cond).reshape(f, 4, h, w))
             k, vt, s, sp = self.controlnet.project_context(ehs)
             self.ctx_cn = (self._static_set("k_cn", k), self._static_set("vt_cn", vt), s, sp)
-            self.cn_scales = self.controlnet._scales(float(conditioning_scale), False, len(self.controlnet.controlnet_down_blocks))
+            self.cn_scales = self.controlnet._scales(float(conditioning_scale), bool(guess_mode), len(self.controlnet.controlnet_down_blocks))
             if self._static.setdefault("cn_scales", self.cn_scales) != self.cn_scales:
                 self._graph = None              # the scale is a launch argument baked into the graph
                 self._static["cn_scales"] = self.cn_scales
@@ -148,7 +157,8 @@ class DenoiseLoop:
                     tails.append(done)
         for ev in tails:
             main.wait_event(ev)
-        ops.cfg_euler_step(eps, self.latents, self.guidance, self.cur, 0, g.batch, g.frames, g.h, g.w)
+        ops.cfg_euler_step(eps, self.latents, self.guidance, self.cur, 0, g.batch, g.frames, g.h, g.w,
+                           self.image_guidance_scale)
 
     def _stream(self, name):
         if not self.overlap_branches:

@@ -70,15 +70,15 @@ class _SVDPipelineCore(PipelineBase):
             ln = nn.LayerNorm(tuple(ehs.shape[1:])).to(device=device, dtype=dtype)      # fresh, gamma=1 beta=0 (:172)
             ehs = ln(ehs)
         if do_classifier_free_guidance:
-            if use_instructpix2pix:
-                raise NotImplementedError("use_instructpix2pix (3-way CFG) is not built")
-            ehs = torch.cat([torch.zeros_like(ehs), ehs])
+            neg = torch.zeros_like(ehs)
+            ehs = torch.cat([ehs, neg, neg]) if use_instructpix2pix else torch.cat([neg, ehs])        # :182-185
         return ehs
 
     def _encode_vae_image(self, image, device, num_videos_per_prompt, do_classifier_free_guidance, use_instructpix2pix=False):
         lat = self.vae.encode(image.to(device=device)).latent_dist.mode()
         if do_classifier_free_guidance:
-            lat = torch.cat([torch.zeros_like(lat), lat])
+            neg = torch.zeros_like(lat)
+            lat = torch.cat([lat, lat, neg]) if use_instructpix2pix else torch.cat([neg, lat])        # :208-211
         return lat.repeat(num_videos_per_prompt, 1, 1, 1)
 
     def _get_add_time_ids(self, fps, motion_bucket_id, noise_aug_strength, dtype, batch_size, num_videos_per_prompt,
@@ -90,7 +90,9 @@ class _SVDPipelineCore(PipelineBase):
             raise ValueError(f"Model expects an added time embedding vector of length {expected}, but a vector of {passed} "
                              "was created. The model has an incorrect config.")
         t = torch.tensor([ids], dtype=dtype).repeat(batch_size * num_videos_per_prompt, 1)
-        return torch.cat([t, t]) if do_classifier_free_guidance else t
+        if not do_classifier_free_guidance:
+            return t
+        return torch.cat([t, t, t]) if use_instructpix2pix else torch.cat([t, t])
 
     def decode_latents(self, latents, num_frames, decode_chunk_size=14):
         import inspect
@@ -138,7 +140,8 @@ class _SVDPipelineCore(PipelineBase):
                   num_inference_steps, min_guidance_scale, max_guidance_scale, fps, motion_bucket_id, noise_aug_strength,
                   decode_chunk_size, num_videos_per_prompt, generator, latents, output_type, callback_on_step_end,
                   callback_on_step_end_tensor_inputs, return_dict, controlnet_conditioning_scale=1.0,
-                  control_guidance_start=0.0, control_guidance_end=1.0):
+                  control_guidance_start=0.0, control_guidance_end=1.0, use_instructpix2pix=False, image_guidance_scale=7.5,
+                  guess_mode=False):
         height = height or self.unet.config.sample_size * self.vae_scale_factor
         width = width or self.unet.config.sample_size * self.vae_scale_factor
         num_frames = num_frames if num_frames is not None else self.unet.config.num_frames
@@ -150,14 +153,15 @@ class _SVDPipelineCore(PipelineBase):
         device = self._execution_device
         do_cfg = max_guidance_scale > 1.0
 
-        ehs = self.encode_clip(image, prompt, use_text, text_encoder, device, num_videos_per_prompt, do_cfg)
+        ip2p = bool(use_instructpix2pix) and do_cfg
+        ehs = self.encode_clip(image, prompt, use_text, text_encoder, device, num_videos_per_prompt, do_cfg, ip2p)
         fps = fps - 1                                                            # SVD was conditioned on fps-1 (:527)
         img = self.image_processor.preprocess(image, height=height, width=width)
         img = img + noise_aug_strength * randn_tensor(img.shape, generator=generator, device=img.device, dtype=img.dtype)
         upcast = self.vae.dtype == torch.float16 and getattr(self.vae.config, "force_upcast", False)
         if upcast:
             self.vae.to(dtype=torch.float32)
-        image_latents = self._encode_vae_image(img.to(self.vae.dtype), device, num_videos_per_prompt, do_cfg).to(ehs.dtype)
+        image_latents = self._encode_vae_image(img.to(self.vae.dtype), device, num_videos_per_prompt, do_cfg, ip2p).to(ehs.dtype)
         image_latents = image_latents.unsqueeze(1).repeat(1, num_frames, 1, 1, 1)
         gesture_latents = None
         if controlnet is not None:
@@ -166,7 +170,7 @@ class _SVDPipelineCore(PipelineBase):
         if upcast:
             self.vae.to(dtype=torch.float16)
         added_time_ids = self._get_add_time_ids(fps, motion_bucket_id, noise_aug_strength, ehs.dtype, batch_size,
-                                                num_videos_per_prompt, do_cfg).to(device)
+                                                num_videos_per_prompt, do_cfg, use_instructpix2pix=ip2p).to(device)
         self.scheduler.set_timesteps(num_inference_steps, device=device)
         timesteps = self.scheduler.timesteps
         latents = self.prepare_latents(batch_size * num_videos_per_prompt, num_frames, self.unet.config.in_channels, height,
@@ -188,7 +192,9 @@ class _SVDPipelineCore(PipelineBase):
         loop.begin(latents=latents, image_latents=image_latents, encoder_hidden_states=ehs, added_time_ids=added_time_ids,
                    guidance_scale=guidance if do_cfg else None, sigmas=self.scheduler.sigmas, timesteps=timesteps,
                    controlnet_cond=gesture_latents, conditioning_scale=float(scale),
-                   controlnet_keep=keep if controlnet is not None else None)
+                   controlnet_keep=keep if controlnet is not None else None,
+                   image_guidance_scale=float(image_guidance_scale) if ip2p else None,
+                   guess_mode=bool(guess_mode) and controlnet is not None)
         with self.progress_bar(total=num_inference_steps) as bar:
             for i, t in enumerate(timesteps):
                 loop.step()
@@ -246,8 +252,6 @@ class StableVideoDiffusionControlNetPipeline(_SVDPipelineCore):
         guess_mode: bool = True,
         image_guidance_scale: float = 7.5,
     ):
-        if use_instructpix2pix:
-            raise NotImplementedError("use_instructpix2pix=True (3-way CFG) is not built; the shipped config sets it False")
         if not isinstance(controlnet, ControlNetModel):
             raise TypeError("controlnet must be a ControlNetModel")
         # the reference wraps both in a one-element list (:485-489), so only scalars work there; a one-element list
@@ -260,11 +264,15 @@ class StableVideoDiffusionControlNetPipeline(_SVDPipelineCore):
         if control_guidance_start >= control_guidance_end or control_guidance_start < 0.0 or control_guidance_end > 1.0:
             raise ValueError(f"control guidance window [{control_guidance_start}, {control_guidance_end}] must satisfy "
                              "0 <= start < end <= 1")
-        if guess_mode and max_guidance_scale > 1.0 and not getattr(self, "_warned_guess", False):
-            # reference: guess_mode + CFG zeroes the uncond residuals (:676-681); inference always passes False
-            raise NotImplementedError("guess_mode=True with CFG is not built (test_code/inference.py passes guess_mode=False)")
+        if guess_mode and max_guidance_scale > 1.0:
+            # reference :676-681 concatenates zeros onto residuals that already have the CFG batch, so the UNet's skip
+            # additions fail on shape; test_code/inference.py always passes guess_mode=False.  Without CFG, guess_mode
+            # only switches the 13 residual scales to logspace(-1, 0, 13) (temporal_controlnet.py:626-630): built.
+            raise NotImplementedError("guess_mode=True with CFG cannot run in the reference either (:676-681); "
+                                      "pass guess_mode=False as test_code/inference.py does")
         return self._generate(image, condition_img, controlnet, prompt, use_text, text_encoder, height, width, num_frames,
                               num_inference_steps, min_guidance_scale, max_guidance_scale, fps, motion_bucket_id,
                               noise_aug_strength, decode_chunk_size, num_videos_per_prompt, generator, latents, output_type,
                               callback_on_step_end, callback_on_step_end_tensor_inputs, return_dict,
-                              controlnet_conditioning_scale, float(control_guidance_start), float(control_guidance_end))
+                              controlnet_conditioning_scale, float(control_guidance_start), float(control_guidance_end),
+                              use_instructpix2pix, image_guidance_scale, guess_mode)
