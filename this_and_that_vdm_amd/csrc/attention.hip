@@ -249,6 +249,18 @@ void launch_attn(const AttnP& p, hipStream_t st) {
   else launch_attn_m<Tag, D, 2>(p, st);
 }
 
+// two 16-bit products accumulated in fp32 in one instruction (v_dot2c_f32_bf16 / v_dot2c_f32_f16): the scores of the
+// temporal kernel need neither operand unpacked
+typedef __attribute__((ext_vector_type(2))) _Float16 tt_half2;
+typedef __attribute__((ext_vector_type(2))) __bf16 tt_bf162;
+template <typename Tag> __device__ __forceinline__ float dot2_acc(unsigned a, unsigned b, float acc);
+template <> __device__ __forceinline__ float dot2_acc<bf16_tag>(unsigned a, unsigned b, float acc) {
+  return __builtin_amdgcn_fdot2_f32_bf16(__builtin_bit_cast(tt_bf162, a), __builtin_bit_cast(tt_bf162, b), acc, false);
+}
+template <> __device__ __forceinline__ float dot2_acc<f16_tag>(unsigned a, unsigned b, float acc) {
+  return __builtin_amdgcn_fdot2(__builtin_bit_cast(tt_half2, a), __builtin_bit_cast(tt_half2, b), acc, false);
+}
+
 // ---------------------------------------------------------------------------------------------
 // temporal self-attention: sequence = frames (<= LPU), one LPU-lane group per (batch, pixel, head).
 // K/V rows of a block's units are staged in LDS (16-B loads), each lane = one query frame.
@@ -263,6 +275,21 @@ __global__ __launch_bounds__(128) void tattn_kernel(const char* qkv, long ldqkv,
   const int tid = threadIdx.x;
   const long total_units = (long)batch * hw * heads;
   const long u0 = (long)blockIdx.x * UPB;
+  // this lane's query row first: its latency overlaps the K/V staging round trip below
+  const int ul = tid / LPU, fi = tid % LPU;
+  const long u = u0 + ul;
+  const bool active = u < total_units && fi < frames;
+  const int h = (int)(u % heads);
+  const long bp = u / heads;
+  const int pix = (int)(bp % hw);
+  const int b = (int)(bp / hw);
+  const long qrow = ((long)b * frames + fi) * hw + pix;
+  uint4 qv[D / 8];           // the query row stays packed: scores are 16-bit dot2 products accumulated in fp32
+  if (active) {
+    const char* qp = qkv + (qrow * ldqkv + h * D) * 2;
+#pragma unroll
+    for (int c = 0; c < D / 8; ++c) qv[c] = *(const uint4*)(qp + c * 16);
+  }
   // stage K and V rows: unit u, frame f
   const int chunks_per_row = D / 8;
   const int nchunks = UPB * frames * chunks_per_row;
@@ -271,34 +298,21 @@ __global__ __launch_bounds__(128) void tattn_kernel(const char* qkv, long ldqkv,
     for (int s = tid; s < nchunks; s += 128) {
       const int c = s % chunks_per_row, rf = s / chunks_per_row;
       const int f = rf % frames, ul = rf / frames;
-      const long u = u0 + ul;
+      const long su = u0 + ul;
       uint4 v = make_uint4(0, 0, 0, 0);
-      if (u < total_units) {
-        const int h = (int)(u % heads);
-        const long bp = u / heads;
-        const int pix = (int)(bp % hw);
-        const int b = (int)(bp / hw);
-        const long row = ((long)b * frames + f) * hw + pix;
-        v = *(const uint4*)(qkv + (row * ldqkv + (tensor + 1) * C + h * D + c * 8) * 2);
+      if (su < total_units) {
+        const int sh = (int)(su % heads);
+        const long sbp = su / heads;
+        const int spix = (int)(sbp % hw);
+        const int sb = (int)(sbp / hw);
+        const long row = ((long)sb * frames + f) * hw + spix;
+        v = *(const uint4*)(qkv + (row * ldqkv + (tensor + 1) * C + sh * D + c * 8) * 2);
       }
       *(uint4*)(dst + ul * UNITB + f * ROWB + c * 16) = v;
     }
   }
   __syncthreads();
-  const int ul = tid / LPU, fi = tid % LPU;
-  const long u = u0 + ul;
-  if (u >= total_units || fi >= frames) return;
-  const int h = (int)(u % heads);
-  const long bp = u / heads;
-  const int pix = (int)(bp % hw);
-  const int b = (int)(bp / hw);
-  const long qrow = ((long)b * frames + fi) * hw + pix;
-  float q[D];
-  {
-    const char* qp = qkv + (qrow * ldqkv + h * D) * 2;
-#pragma unroll
-    for (int c = 0; c < D / 8; ++c) unpack8<Tag>(*(const uint4*)(qp + c * 16), q + c * 8);
-  }
+  if (!active) return;
   const char* ks = smem + ul * UNITB;
   const char* vs = smem + UPB * UNITB + ul * UNITB;
   float sc[LPU];
@@ -307,14 +321,16 @@ __global__ __launch_bounds__(128) void tattn_kernel(const char* qkv, long ldqkv,
   for (int j = 0; j < LPU; ++j) {
     float a = 0.f;
     if (j < frames) {
+      float a1 = 0.f;        // two accumulation chains
 #pragma unroll
       for (int c = 0; c < D / 8; ++c) {
-        float kf[8];
-        unpack8<Tag>(*(const uint4*)(ks + j * ROWB + c * 16), kf);
-#pragma unroll
-        for (int e = 0; e < 8; ++e) a = fmaf(q[c * 8 + e], kf[e], a);
+        const uint4 kv = *(const uint4*)(ks + j * ROWB + c * 16);
+        a = dot2_acc<Tag>(qv[c].x, kv.x, a);
+        a1 = dot2_acc<Tag>(qv[c].y, kv.y, a1);
+        a = dot2_acc<Tag>(qv[c].z, kv.z, a);
+        a1 = dot2_acc<Tag>(qv[c].w, kv.w, a1);
       }
-      a *= scale_log2e;
+      a = (a + a1) * scale_log2e;
       mx = fmaxf(mx, a);
     }
     sc[j] = a;
@@ -323,7 +339,7 @@ __global__ __launch_bounds__(128) void tattn_kernel(const char* qkv, long ldqkv,
 #pragma unroll
   for (int j = 0; j < LPU; ++j) { sc[j] = j < frames ? exp2f(sc[j] - mx) : 0.f; sum += sc[j]; }
   const float inv = 1.0f / sum;
-  float* acc = q;            // reuse registers
+  float acc[D];
 #pragma unroll
   for (int e = 0; e < D; ++e) acc[e] = 0.f;
 #pragma unroll
