@@ -154,6 +154,47 @@ def cpu_baseline(mode, res):
                       f"{mode.upper()} denoise step, CFG batch 2 x {FRAMES} frames at {h}x{w} latents = {step_s:.1f} s"}
 
 
+def self_launch(n: int) -> int:
+    """`python bench.py --gpus N` without a launcher: re-exec this script under torch.distributed.run with one rank per
+    GPU of this node (127.0.0.1 rendezvous on a free port) -- exactly the command line the driver uses for N > 1."""
+    import socket
+    import subprocess
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    return subprocess.call(cmd, env=env)
+
+
+def stub_cpu_main(a, world: int, rank: int) -> int:
+    """The rank plumbing of main() (rendezvous, barrier-bracketed timing, max over ranks, rank-0 JSON line) with the GPU
+    loop replaced by a sleep, on gloo.  Exists only so the N > 1 launcher path is testable without GPUs."""
+    import torch.distributed as dist
+    from this_and_that_vdm_amd.dist import max_over_ranks
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("gloo")
+        dist.barrier()
+    t0 = time.perf_counter()
+    time.sleep(0.002 * a.steps * (1 + rank))
+    if world > 1:
+        dist.barrier()
+    dt = max_over_ranks(time.perf_counter() - t0, "cpu")
+    if rank == 0:
+        print(json.dumps({"metric": "stub (launcher self-test, no GPU work)", "value": world * a.steps / dt,
+                          "unit": "denoise-steps/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
+                          "ms_per_step": dt / a.steps * 1e3, "higher_is_better": True, "scaling": "weak",
+                          "vs_baseline": None, "dtype": a.dtype, "data": "none", "config": {"workload": "stub"},
+                          "roofline": None, "cpu_baseline": None}))
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+    return 0
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -164,13 +205,19 @@ def main():
     ap.add_argument("--dtype", choices=["bf16", "fp16"], default="bf16")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-kernel-profile", action="store_true")
+    ap.add_argument("--stub-cpu", action="store_true",
+                    help="launcher self-test (tests/test_bench_launch_cpu.py): gloo ranks time a sleep instead of the GPU loop")
     a = ap.parse_args()
 
+    if a.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        raise SystemExit(self_launch(a.gpus))            # `python bench.py --gpus N`: spawn one rank per GPU ourselves
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
     if world != a.gpus:
         raise SystemExit(f"--gpus {a.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run --nproc-per-node {a.gpus}")
+    if a.stub_cpu:
+        return stub_cpu_main(a, world, rank)
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs MI355X GPUs (the denoise path has no CPU fallback)")
     torch.cuda.set_device(local)

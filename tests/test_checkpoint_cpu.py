@@ -58,3 +58,113 @@ def test_cpu_forward_fails_loudly():
     m = UNetSpatioTemporalConditionModel(**KW)
     with pytest.raises(RuntimeError, match="no CPU fallback"):
         m(torch.zeros(1, 3, 8, 8, 8), 1.0, torch.zeros(1, 2, 32), torch.zeros(1, 3))
+
+
+def test_from_unet_is_callable_on_meta_device():
+    """The real classmethod (temporal_controlnet.py:311-339): ControlNet built with ITS OWN defaults (heads (5,10,20,20),
+    quirk Q2) and fed the UNet's time/down/mid weights by name -- shapes are head-independent, so the default-ctor UNet
+    (heads (5,10,10,20)) loads.  Meta tensors: no 2.2 B-parameter allocation."""
+    with torch.device("meta"):
+        u = UNetSpatioTemporalConditionModel()
+        c = ControlNetModel.from_unet(u)
+    assert isinstance(c, ControlNetModel) and c.config.num_attention_heads == (5, 10, 20, 20)
+    assert u.config.num_attention_heads == (5, 10, 10, 20)
+    assert sum(p.numel() for p in c.parameters()) == 680_946_577
+    assert c.conv_in_concat.weight.shape == (320, 12, 3, 3) and len(c.controlnet_down_blocks) == 12
+    su, sc = u.down_blocks.state_dict(), c.down_blocks.state_dict()
+    assert su.keys() == sc.keys() and all(su[k].shape == sc[k].shape for k in su)
+
+
+def test_sharded_and_variant_checkpoints_load(tmp_path):
+    """diffusers writes big models as shards + diffusion_pytorch_model.safetensors.index.json, and fp16 variants as
+    diffusion_pytorch_model.fp16.safetensors: both must load to the same state dict."""
+    from safetensors.torch import save_file
+    m = UNetSpatioTemporalConditionModel(**KW)
+    fill_parameters_(m, "unet.")
+    sd = {k: v.contiguous() for k, v in m.state_dict().items()}
+    folder = os.path.join(tmp_path, "unet")
+    m.save_pretrained(folder)
+    os.remove(os.path.join(folder, "diffusion_pytorch_model.safetensors"))
+    keys = sorted(sd)
+    half = len(keys) // 2
+    shards = {"diffusion_pytorch_model-00001-of-00002.safetensors": keys[:half],
+              "diffusion_pytorch_model-00002-of-00002.safetensors": keys[half:]}
+    for name, ks in shards.items():
+        save_file({k: sd[k] for k in ks}, os.path.join(folder, name), metadata={"format": "pt"})
+    json.dump({"metadata": {}, "weight_map": {k: n for n, ks in shards.items() for k in ks}},
+              open(os.path.join(folder, "diffusion_pytorch_model.safetensors.index.json"), "w"))
+    m2 = UNetSpatioTemporalConditionModel.from_pretrained(str(tmp_path), subfolder="unet")
+    assert all(torch.equal(sd[k], v) for k, v in m2.state_dict().items())
+    # a shard named by the index but absent on disk is an error, not a partial load
+    os.remove(os.path.join(folder, "diffusion_pytorch_model-00002-of-00002.safetensors"))
+    with pytest.raises(OSError, match="missing"):
+        UNetSpatioTemporalConditionModel.from_pretrained(str(tmp_path), subfolder="unet")
+    # variant="fp16"
+    save_file({k: v.half() for k, v in sd.items()}, os.path.join(folder, "diffusion_pytorch_model.fp16.safetensors"))
+    m3 = UNetSpatioTemporalConditionModel.from_pretrained(str(tmp_path), subfolder="unet", variant="fp16", torch_dtype=torch.float16)
+    assert m3.dtype == torch.float16 and all(torch.equal(sd[k].half(), v) for k, v in m3.state_dict().items())
+
+
+def test_pipeline_from_pretrained_reads_the_local_hub_folder(tmp_path):
+    """test_code/inference.py:171-178 passes vae / image_encoder / unet and lets from_pretrained find feature_extractor/ and
+    scheduler/ in the folder.  The CLIP normalisation must be the reference formula (:134-156): (x - mean) / std on the
+    antialias-resized [0,1] image -- and it must never be skipped silently."""
+    from tests.stubs import StubCLIPVision, StubVAE
+    from this_and_that_vdm_amd.svd import StableVideoDiffusionControlNetPipeline
+    from this_and_that_vdm_amd.svd.pipeline_utils import CLIPFeatureExtractor, resize_with_antialiasing
+    root = str(tmp_path)
+    u = UNetSpatioTemporalConditionModel(**KW)
+    u.save_pretrained(os.path.join(root, "unet"))
+    os.makedirs(os.path.join(root, "feature_extractor"))
+    os.makedirs(os.path.join(root, "scheduler"))
+    mean, std = [0.5, 0.4, 0.3], [0.2, 0.25, 0.3]          # deliberately NOT the CLIP defaults: proves the file is read
+    json.dump({"image_processor_type": "CLIPImageProcessor", "do_normalize": True, "image_mean": mean, "image_std": std,
+               "size": {"shortest_edge": 224}}, open(os.path.join(root, "feature_extractor", "preprocessor_config.json"), "w"))
+    json.dump({"_class_name": "EulerDiscreteScheduler", "_diffusers_version": "0.24.0", "beta_start": 0.00085, "beta_end": 0.012,
+               "beta_schedule": "scaled_linear", "num_train_timesteps": 1000, "prediction_type": "v_prediction",
+               "interpolation_type": "linear", "use_karras_sigmas": True, "sigma_min": 0.002, "sigma_max": 650.0,
+               "timestep_spacing": "leading", "timestep_type": "continuous", "steps_offset": 1, "trained_betas": None,
+               "clip_sample": False, "set_alpha_to_one": False, "skip_prk_steps": True},
+              open(os.path.join(root, "scheduler", "scheduler_config.json"), "w"))
+    seen = {}
+
+    class Clip(StubCLIPVision):
+        def forward(self, image):
+            seen["pixel_values"] = image.detach().clone()
+            return super().forward(image)
+
+    pipe = StableVideoDiffusionControlNetPipeline.from_pretrained(root, vae=StubVAE(), image_encoder=Clip(), unet=u)
+    assert pipe.feature_extractor.image_mean == mean and pipe.scheduler.config.sigma_max == 650.0
+    import numpy as np
+    import PIL.Image
+    arr = (np.random.default_rng(0).random((48, 80, 3)) * 255).astype("uint8")
+    ehs = pipe.encode_clip(PIL.Image.fromarray(arr), None, False, None, "cpu", 1, True)
+    x = torch.from_numpy(arr.astype("float32") / 255.0).permute(2, 0, 1)[None]
+    want = (resize_with_antialiasing(x * 2.0 - 1.0, (224, 224)) + 1.0) / 2.0
+    want = (want - torch.tensor(mean).view(1, 3, 1, 1)) / torch.tensor(std).view(1, 3, 1, 1)
+    torch.testing.assert_close(seen["pixel_values"], want, rtol=1e-6, atol=1e-6)
+    assert ehs.shape[0] == 2 and float(ehs[0].abs().max()) == 0.0
+    # unet can come from the folder too
+    pipe2 = StableVideoDiffusionControlNetPipeline.from_pretrained(root, vae=StubVAE(), image_encoder=Clip())
+    assert pipe2.unet.config.block_out_channels == (64, 64, 64, 64)
+    # no folder: CLIP's published constants, never "no normalisation"
+    pipe3 = StableVideoDiffusionControlNetPipeline.from_pretrained(None, vae=StubVAE(), image_encoder=Clip(), unet=u)
+    assert pipe3.feature_extractor.image_mean == CLIPFeatureExtractor().image_mean
+    pipe3.feature_extractor = None
+    with pytest.raises(RuntimeError, match="feature_extractor"):
+        pipe3.encode_clip(PIL.Image.fromarray(arr), None, False, None, "cpu", 1, True)
+
+
+def test_clip_feature_extractor_matches_transformers():
+    """Same numbers as transformers.CLIPImageProcessor for the call the reference makes (:145-152)."""
+    transformers = pytest.importorskip("transformers")
+    from this_and_that_vdm_amd.svd.pipeline_utils import CLIPFeatureExtractor
+    x = torch.rand(2, 3, 224, 224, generator=torch.Generator().manual_seed(0))
+    ours = CLIPFeatureExtractor()(images=x, do_normalize=True, do_center_crop=False, do_resize=False, do_rescale=False,
+                                  return_tensors="pt").pixel_values
+    try:
+        theirs = transformers.CLIPImageProcessor()(images=x, do_normalize=True, do_center_crop=False, do_resize=False,
+                                                   do_rescale=False, return_tensors="pt").pixel_values
+    except Exception as e:          # an image-processor backend (PIL/torchvision) this image lacks
+        pytest.skip(f"transformers CLIPImageProcessor unusable here: {e}")
+    torch.testing.assert_close(ours, theirs, rtol=1e-5, atol=1e-5)

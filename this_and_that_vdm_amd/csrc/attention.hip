@@ -232,11 +232,8 @@ __global__ __launch_bounds__(256) void attn_kernel(const AttnP p) {
 template <typename Tag, int D, int MASK>
 void launch_attn_m(const AttnP& p, hipStream_t st) {
   constexpr size_t lds = 2 * (KB * D * 2 + D * KB * 2);
-  static bool attr_done = false;
-  if (!attr_done) {
-    (void)hipFuncSetAttribute((const void*)attn_kernel<Tag, D, MASK>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    attr_done = true;
-  }
+  static unsigned long long attr_done = 0;
+  tt_lds_opt_in((const void*)attn_kernel<Tag, D, MASK>, (int)lds, &attr_done);
   // mask 2: one block per (query residue class, QB queries of that class)
   const int cls = MASK == 2 ? p.ctx_batches : 1;
   const dim3 grid(cls * ((((p.lq + cls - 1) / cls) + QB - 1) / QB), p.heads, p.nseq);
@@ -364,11 +361,8 @@ template <typename Tag, int D, int LPU>
 void launch_tattn(const void* qkv, long ldqkv, void* out, long ldo, int batch, int frames, int hw, int heads, hipStream_t st) {
   constexpr int UPB = 128 / LPU;
   constexpr size_t lds = 2 * UPB * (LPU * (D * 2 + 16) + 64);
-  static bool attr_done = false;
-  if (!attr_done) {
-    (void)hipFuncSetAttribute((const void*)tattn_kernel<Tag, D, LPU>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    attr_done = true;
-  }
+  static unsigned long long attr_done = 0;
+  tt_lds_opt_in((const void*)tattn_kernel<Tag, D, LPU>, (int)lds, &attr_done);
   const long units = (long)batch * hw * heads;
   const float sl2 = 1.4426950408889634f / sqrtf((float)D);
   hipLaunchKernelGGL((tattn_kernel<Tag, D, LPU>), dim3((unsigned)((units + UPB - 1) / UPB)), dim3(128), lds, st,

@@ -20,7 +20,20 @@ static __device__ __attribute__((aligned(64))) unsigned int tt_zero_page[64] = {
 
 void tt_set_error(const char* fmt, ...);
 #define TT_FAIL(code, ...) do { tt_set_error(__VA_ARGS__); return (code); } while (0)
+// Kernels that need more than the default 64 KiB of dynamic LDS opt in with hipFuncSetAttribute.  The attribute is per
+// DEVICE, so the "done" flag is a per-device bit mask (one mask per kernel instance), and a failure is kept in
+// tt_attr_err until the entry point's TT_CHECK_LAUNCH reports it (a launch without the opt-in would fail anyway).
+static thread_local hipError_t tt_attr_err = hipSuccess;
+static inline void tt_lds_opt_in(const void* fn, int bytes, unsigned long long* done_mask) {
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess) dev = 0;
+  if (dev >= 0 && dev < 64 && ((*done_mask >> dev) & 1ull)) return;
+  const hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
+  if (e != hipSuccess) { tt_attr_err = e; return; }
+  if (dev >= 0 && dev < 64) *done_mask |= 1ull << dev;
+}
 #define TT_CHECK_LAUNCH(name) do { hipError_t e_ = hipGetLastError(); \
+    if (tt_attr_err != hipSuccess) { e_ = tt_attr_err; tt_attr_err = hipSuccess; } \
     if (e_ != hipSuccess) TT_FAIL(TT_ELAUNCH, "%s: %s", name, hipGetErrorString(e_)); } while (0)
 
 // ---------------------------------------------------------------- scalar conversions

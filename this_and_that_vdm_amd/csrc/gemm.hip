@@ -826,12 +826,8 @@ void launch_mode(const GemmP& p, hipStream_t st) {
   constexpr int NT_ = 64 * WGM * WGN, CPR_ = BK / 8;
   constexpr size_t lds = (size_t)NST * (((BM * CPR_ + NT_ - 1) / NT_) + ((BN * CPR_ + NT_ - 1) / NT_)) * NT_ * 16;
   static_assert(lds <= 160 * 1024, "LDS ring exceeds 160 KiB");
-  static bool attr_done = false;     // one flag per kernel instance: opt in to the full dynamic-LDS size once
-  if (!attr_done) {
-    (void)hipFuncSetAttribute((const void*)gemm_kernel<Tag, BM, BN, BK, NST, WGM, WGN, MODE>,
-                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    attr_done = true;
-  }
+  static unsigned long long attr_done = 0;     // per kernel instance, one bit per device (see tt_lds_opt_in)
+  tt_lds_opt_in((const void*)gemm_kernel<Tag, BM, BN, BK, NST, WGM, WGN, MODE>, (int)lds, &attr_done);
   hipLaunchKernelGGL((gemm_kernel<Tag, BM, BN, BK, NST, WGM, WGN, MODE>), dim3(p.tiles_m * p.tiles_n * p.splitk),
                      dim3(64 * WGM * WGN), lds, st, p);
   if (p.splitk > 1) {
@@ -1003,11 +999,8 @@ template <typename Tag, bool HAS_RES>
 void launch_sq320(const GemmP& p, hipStream_t st) {
   constexpr size_t lds = (size_t)(HAS_RES ? 3 * 2 * SQ_TILE_BYTES : 5 * SQ_TILE_BYTES) + SQ_WAVES * 4096;
   static_assert(lds <= 160 * 1024, "sq320 LDS");
-  static bool attr_done = false;
-  if (!attr_done) {
-    (void)hipFuncSetAttribute((const void*)sq320_kernel<Tag, HAS_RES>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    attr_done = true;
-  }
+  static unsigned long long attr_done = 0;
+  tt_lds_opt_in((const void*)sq320_kernel<Tag, HAS_RES>, (int)lds, &attr_done);
   const int ntiles = (p.m + SQ_ROWS - 1) / SQ_ROWS;
   hipLaunchKernelGGL((sq320_kernel<Tag, HAS_RES>), dim3(ntiles < 256 ? ntiles : 256), dim3(SQ_NT), lds, st, p);
 }

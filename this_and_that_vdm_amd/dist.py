@@ -24,6 +24,8 @@ def flat_param_buffer(model: torch.nn.Module) -> torch.Tensor:
         flat[off:off + n].copy_(p.data.reshape(-1))
         p.data = flat[off:off + n].view_as(p)
         off += n
+    if hasattr(model, "invalidate_packs"):
+        model.invalidate_packs()             # kernel-ready weight packs were built from the old storage
     return flat
 
 
@@ -38,6 +40,8 @@ def broadcast_model_(model: torch.nn.Module, src: int = 0, flat: Optional[torch.
     dist.broadcast(flat, src=src)
     if flat.is_cuda:
         torch.cuda.synchronize()
+    if hasattr(model, "invalidate_packs"):
+        model.invalidate_packs()             # the broadcast wrote through .data: _version did not move
     return time.perf_counter() - t0
 
 

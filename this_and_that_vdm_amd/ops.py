@@ -33,15 +33,20 @@ def _prof_end(start, name, flops, shape=None):
 
 
 _WS = {}
+_WS_RETIRED = []          # outgrown buffers stay allocated: a captured hipGraph may still hold their address
+WS_FLOOR_BYTES = 64 << 20
 
 
 def _workspace(nbytes: int, device) -> torch.Tensor:
-    """Persistent split-K scratch per device (grown on demand; sized during warm-up, so a captured graph keeps a
-    stable pointer).  Launches on one stream are ordered, so every GEMM can share it."""
+    """Persistent split-K scratch per (device, stream), grown on demand.  Launches on one stream are ordered, so every
+    GEMM on it can share the buffer.  A buffer that has been handed out is NEVER freed: a hipGraph captured earlier keeps
+    its raw pointer, so an outgrown buffer is retired (kept alive) instead of dropped."""
     key = (device, torch.cuda.current_stream().cuda_stream)      # per stream: concurrent branches must not share slabs
     buf = _WS.get(key)
     if buf is None or buf.numel() < nbytes:
-        buf = _WS[key] = torch.empty(max(nbytes, 64 << 20), dtype=torch.uint8, device=device)
+        if buf is not None:
+            _WS_RETIRED.append(buf)
+        buf = _WS[key] = torch.empty(max(nbytes, WS_FLOOR_BYTES), dtype=torch.uint8, device=device)
     return buf
 
 

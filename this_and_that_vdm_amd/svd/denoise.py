@@ -58,9 +58,14 @@ class DenoiseLoop:
             raise ValueError("a CFG batch of 3 (use_instructpix2pix) needs guidance_scale and image_guidance_scale")
         self.image_guidance_scale = float(image_guidance_scale) if b == 3 else None
         dtype = self.unet._run_dtype()
+        if self.controlnet is not None:
+            self.controlnet.prepare()
+        # a captured graph holds raw pointers into the models' packed weights: the pack generation of both models is part
+        # of the key, so load_state_dict / .to() / in-place updates between requests drop the stale graphs
+        packs = (id(self.unet), self.unet._pack_gen) + ((id(self.controlnet), self.controlnet._pack_gen) if self.controlnet is not None else ())
         key = (b, f, h, w, dtype, self.controlnet is not None, tuple(encoder_hidden_states.shape), len(timesteps),
-               guidance_scale is not None, self.image_guidance_scale)          # the image scale is baked into the graph
-        if key != self._key:                    # new shapes: new static buffers, new graph
+               guidance_scale is not None, self.image_guidance_scale, packs)   # the image scale is baked into the graph
+        if key != self._key:                    # new shapes or new weights: new static buffers, new graph
             self._graph, self._graph_off, self._key, self._static = None, None, key, {}
         self.geom, self.dtype = Geom(b, f, h, w), dtype
         f32 = lambda t: t.to(device=dev, dtype=torch.float32).contiguous()

@@ -30,9 +30,18 @@ class DenoiserBase(ModelMixin):
     compute_dtype: Optional[torch.dtype] = None      # None: parameter dtype if 16-bit, else bf16
 
     # ---- packing
+    _pack_gen = 0          # bumped by every (re)pack: consumers holding raw pointers to packed buffers (captured
+                           # hipGraphs in DenoiseLoop) compare it to know their pointers went stale
+
     def _pack_key(self):
+        # _version catches in-place updates and load_state_dict; data_ptr catches `.data` re-homing (dist.flat_param_buffer),
+        # whose later writes through the flat buffer do NOT bump _version -- dist.broadcast_model_ also invalidates explicitly
         p0 = next(self.parameters())
-        return (p0.device, self._run_dtype(), sum(p._version for p in self.parameters()))
+        return (p0.device, self._run_dtype(), sum(p._version for p in self.parameters()), p0.data_ptr())
+
+    def invalidate_packs(self):
+        """Force the next prepare() to repack (call after writing parameters through ``.data`` or an aliasing buffer)."""
+        self._packed_key = None
 
     def _run_dtype(self) -> torch.dtype:
         if self.compute_dtype is not None:
@@ -56,6 +65,7 @@ class DenoiserBase(ModelMixin):
         self._k_w = torch.cat(reg.k_w, 0).to(dtype).contiguous()
         self._v_w = torch.cat(reg.v_w, 0).to(dtype).contiguous()
         self._packed_key = self._pack_key()
+        self._pack_gen = self._pack_gen + 1
         return self
 
     def _pack_modules(self, reg: PackRegistry, dtype):

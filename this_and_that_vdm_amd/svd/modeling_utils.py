@@ -21,6 +21,36 @@ WEIGHTS_NAME = "diffusion_pytorch_model.safetensors"
 WEIGHTS_NAME_BIN = "diffusion_pytorch_model.bin"
 
 
+def _load_weights(path: str, variant: str = None) -> Dict[str, torch.Tensor]:
+    """State dict of a diffusers model folder: a single ``diffusion_pytorch_model[.variant].safetensors`` / ``.bin``, or
+    a sharded checkpoint described by ``diffusion_pytorch_model.safetensors.index[.variant].json`` (``weight_map``:
+    parameter name -> shard file), as diffusers' save_pretrained(max_shard_size=...) writes it."""
+    stem = "diffusion_pytorch_model" + (f".{variant}" if variant else "")
+    st_file, bin_file = os.path.join(path, stem + ".safetensors"), os.path.join(path, stem + ".bin")
+    index = os.path.join(path, "diffusion_pytorch_model.safetensors.index" + (f".{variant}" if variant else "") + ".json")
+    if os.path.isfile(st_file):
+        from safetensors.torch import load_file
+        return load_file(st_file)
+    if os.path.isfile(index):
+        from safetensors.torch import load_file
+        with open(index) as f:
+            weight_map = json.load(f)["weight_map"]
+        sd: Dict[str, torch.Tensor] = {}
+        for shard in sorted(set(weight_map.values())):
+            shard_file = os.path.join(path, shard)
+            if not os.path.isfile(shard_file):
+                raise OSError(f"{index} names shard {shard}, which is missing under {path}")
+            part = load_file(shard_file)
+            sd.update({k: v for k, v in part.items() if weight_map.get(k) == shard})
+        absent = [k for k in weight_map if k not in sd]
+        if absent:
+            raise OSError(f"sharded checkpoint under {path}: {len(absent)} tensors named by the index are in no shard, e.g. {absent[:3]}")
+        return sd
+    if os.path.isfile(bin_file):
+        return torch.load(bin_file, map_location="cpu")
+    raise OSError(f"no weights file ({stem}.safetensors | .bin | safetensors index) under {path}")
+
+
 class FrozenDict(OrderedDict):
     """dict with attribute access (``unet.config.in_channels``; pipeline...controlnet.py:236,493,588)."""
 
@@ -114,15 +144,7 @@ class ModelMixin(nn.Module):
         init_kwargs = {k: (tuple(v) if isinstance(v, list) else v) for k, v in cfg.items() if k in accepted}
         init_kwargs.update({k: v for k, v in kwargs.items() if k in accepted})
         model = cls(**init_kwargs)
-        stem = "diffusion_pytorch_model" + (f".{variant}" if variant else "")
-        st_file, bin_file = os.path.join(path, stem + ".safetensors"), os.path.join(path, stem + ".bin")
-        if os.path.isfile(st_file):
-            from safetensors.torch import load_file
-            sd = load_file(st_file)
-        elif os.path.isfile(bin_file):
-            sd = torch.load(bin_file, map_location="cpu")
-        else:
-            raise OSError(f"no weights file ({stem}.safetensors|.bin) under {path}")
+        sd = _load_weights(path, variant)
         missing, unexpected = model.load_state_dict(sd, strict=False)
         if missing or unexpected:
             raise RuntimeError(f"state dict mismatch loading {cls.__name__}: missing={missing[:5]} unexpected={unexpected[:5]}")

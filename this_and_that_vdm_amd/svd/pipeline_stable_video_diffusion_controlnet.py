@@ -6,9 +6,10 @@ Kept: the ``__call__`` surface and argument meaning, CLIP(+text) context with th
 LayerNorm((78,1024)) (reference :165-173), un-scaled VAE ``.mode()`` latents (:200), CFG order [uncond, cond]
 (:177-185,203-211), fps-1 / motion bucket / noise-aug time ids, per-frame guidance ramp, ``output_type="latent"``,
 ``latents=``, ``generator=``, ``callback_on_step_end``.
-Changed on purpose: the gesture map is VAE-encoded ONCE instead of inside every step (reference :652 --
-loop-invariant, identical values), and ``use_instructpix2pix`` / ``guess_mode`` CFG variants are not built
-(the shipped configuration has both False: config/train_image2video_gesturenet.yaml:78,81)."""
+``use_instructpix2pix`` (CFG batch of 3, reference :182-184,208-210,698-702) and ``guess_mode`` without CFG are built;
+``guess_mode`` with CFG raises, as the reference's branch (:676-681) cannot run either.
+Changed on purpose: the gesture map is VAE-encoded ONCE per request instead of inside every step (reference :652 --
+loop-invariant), in the VAE's own dtype after the force_upcast window, exactly where the reference encodes it."""
 from __future__ import annotations
 
 from typing import Callable, Dict, List, Optional, Union
@@ -19,8 +20,8 @@ import torch
 import torch.nn as nn
 
 from .denoise import DenoiseLoop
-from .pipeline_utils import (PipelineBase, StableVideoDiffusionPipelineOutput, VaeImageProcessor, append_dims, randn_tensor,
-                             resize_with_antialiasing, tensor2vid)
+from .pipeline_utils import (CLIPFeatureExtractor, PipelineBase, StableVideoDiffusionPipelineOutput, VaeImageProcessor,
+                             append_dims, randn_tensor, resize_with_antialiasing, tensor2vid)
 from .temporal_controlnet import ControlNetModel
 
 
@@ -39,16 +40,31 @@ class _SVDPipelineCore(PipelineBase):
 
     @classmethod
     def from_pretrained(cls, pretrained_model_name_or_path=None, *, vae=None, image_encoder=None, unet=None, scheduler=None,
-                        feature_extractor=None, **kwargs):
-        """The reference passes vae/image_encoder/unet explicitly (test_code/inference.py:171-180) and lets diffusers
-        load scheduler + feature extractor from the hub folder.  Here every component must be supplied except the
-        scheduler (defaults to SVD's EulerDiscrete configuration): there is no hub access and no diffusers in this image."""
+                        feature_extractor=None, torch_dtype=None, **kwargs):
+        """The reference passes vae / image_encoder / unet explicitly (test_code/inference.py:171-178) and lets diffusers
+        load the remaining components from the hub folder.  Same here, from a LOCAL diffusers-format folder (no network):
+          feature_extractor/preprocessor_config.json -> CLIP image processor (mean/std used by ``encode_clip``, reference :145-152)
+          scheduler/scheduler_config.json            -> EulerDiscreteScheduler
+          unet/                                      -> UNetSpatioTemporalConditionModel (only if ``unet`` is not passed)
+        vae and image_encoder are third-party models (AutoencoderKLTemporalDecoder / CLIPVisionModelWithProjection) and must be
+        passed in.  Without a folder the scheduler defaults to SVD's shipped EulerDiscrete configuration and the feature
+        extractor to CLIP's published preprocessing constants; nothing is ever silently skipped."""
+        import os
+        path = pretrained_model_name_or_path
+        have_dir = isinstance(path, str) and os.path.isdir(path)
+        if unet is None and have_dir and os.path.isdir(os.path.join(path, "unet")):
+            from .unet_spatio_temporal_condition import UNetSpatioTemporalConditionModel
+            unet = UNetSpatioTemporalConditionModel.from_pretrained(path, subfolder="unet", torch_dtype=torch_dtype)
         missing = [n for n, v in (("vae", vae), ("image_encoder", image_encoder), ("unet", unet)) if v is None]
         if missing:
             raise ValueError(f"{cls.__name__}.from_pretrained needs these components passed in: {missing}")
         if scheduler is None:
             from .scheduling_euler_discrete import EulerDiscreteScheduler
-            scheduler = EulerDiscreteScheduler()
+            cfg = os.path.join(path, "scheduler", "scheduler_config.json") if have_dir else None
+            scheduler = EulerDiscreteScheduler.from_config(cfg) if cfg and os.path.isfile(cfg) else EulerDiscreteScheduler()
+        if feature_extractor is None:
+            cfg = os.path.join(path, "feature_extractor", "preprocessor_config.json") if have_dir else None
+            feature_extractor = CLIPFeatureExtractor.from_json_file(cfg) if cfg and os.path.isfile(cfg) else CLIPFeatureExtractor()
         return cls(vae=vae, image_encoder=image_encoder, unet=unet, scheduler=scheduler, feature_extractor=feature_extractor)
 
     # ---- constants of a request (reference :130-254,305-337)
@@ -58,9 +74,12 @@ class _SVDPipelineCore(PipelineBase):
         if not isinstance(image, torch.Tensor):
             image = self.image_processor.numpy_to_pt(self.image_processor.pil_to_numpy(image))
             image = (resize_with_antialiasing(image * 2.0 - 1.0, (224, 224)) + 1.0) / 2.0
-            if self.feature_extractor is not None:
-                image = self.feature_extractor(images=image, do_normalize=True, do_center_crop=False, do_resize=False,
-                                               do_rescale=False, return_tensors="pt").pixel_values
+            if self.feature_extractor is None:
+                raise RuntimeError("encode_clip: the pipeline has no feature_extractor, so the CLIP mean/std normalisation the "
+                                   "reference always applies (:145-152) cannot be done; build the pipeline with from_pretrained() "
+                                   "or pass feature_extractor=CLIPFeatureExtractor()")
+            image = self.feature_extractor(images=image, do_normalize=True, do_center_crop=False, do_resize=False,
+                                           do_rescale=False, return_tensors="pt").pixel_values
         emb = self.image_encoder(image.to(device=device, dtype=dtype)).image_embeds.unsqueeze(1)
         bs, seq, _ = emb.shape
         ehs = emb.repeat(1, num_videos_per_prompt, 1).view(bs * num_videos_per_prompt, seq, -1)
@@ -163,12 +182,14 @@ class _SVDPipelineCore(PipelineBase):
             self.vae.to(dtype=torch.float32)
         image_latents = self._encode_vae_image(img.to(self.vae.dtype), device, num_videos_per_prompt, do_cfg, ip2p).to(ehs.dtype)
         image_latents = image_latents.unsqueeze(1).repeat(1, num_frames, 1, 1, 1)
-        gesture_latents = None
-        if controlnet is not None:
-            cond = self.prepare_condition_image(condition_img, device)
-            gesture_latents = self.vae.encode(cond.to(self.vae.dtype)).latent_dist.mode()     # once, not per step (Q6)
         if upcast:
             self.vae.to(dtype=torch.float16)
+        gesture_latents = None
+        if controlnet is not None:
+            # after the cast-back, in the VAE's own dtype: where (and in which precision) the reference encodes it (:652),
+            # but once per request instead of once per step (loop-invariant, quirk Q6)
+            cond = self.prepare_condition_image(condition_img, device)
+            gesture_latents = self.vae.encode(cond.to(self.vae.dtype)).latent_dist.mode()
         added_time_ids = self._get_add_time_ids(fps, motion_bucket_id, noise_aug_strength, ehs.dtype, batch_size,
                                                 num_videos_per_prompt, do_cfg, use_instructpix2pix=ip2p).to(device)
         self.scheduler.set_timesteps(num_inference_steps, device=device)
@@ -187,7 +208,7 @@ class _SVDPipelineCore(PipelineBase):
 
         key = controlnet is not None
         loop = self._loops.get(key)
-        if loop is None or loop.controlnet is not controlnet:
+        if loop is None or loop.controlnet is not controlnet or loop.unet is not self.unet:
             loop = self._loops[key] = DenoiseLoop(self.unet, controlnet, use_graph=True)
         loop.begin(latents=latents, image_latents=image_latents, encoder_hidden_states=ehs, added_time_ids=added_time_ids,
                    guidance_scale=guidance if do_cfg else None, sigmas=self.scheduler.sigmas, timesteps=timesteps,

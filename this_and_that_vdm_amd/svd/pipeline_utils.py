@@ -127,6 +127,45 @@ def resize_with_antialiasing(img: torch.Tensor, size, interpolation: str = "bicu
     return F.interpolate(out, size=size, mode=interpolation, align_corners=align_corners)
 
 
+class _PixelValues(dict):
+    """BatchFeature-like: ``.pixel_values`` and ``["pixel_values"]``."""
+
+    def __getattr__(self, k):
+        try:
+            return self[k]
+        except KeyError as e:
+            raise AttributeError(k) from e
+
+
+class CLIPFeatureExtractor:
+    """The slice of transformers.CLIPImageProcessor the pipelines call (reference :145-152): per-channel
+    ``(x - image_mean) / image_std`` on an already resized, already [0,1] tensor batch.  Constants default to OpenAI CLIP's
+    published preprocessing (what stabilityai/stable-video-diffusion-img2vid ships in feature_extractor/
+    preprocessor_config.json); ``from_json_file`` reads a local preprocessor_config.json.  A transformers
+    CLIPImageProcessor instance can be passed to the pipelines instead -- the call signature is the same."""
+
+    def __init__(self, image_mean=(0.48145466, 0.4578275, 0.40821073), image_std=(0.26862954, 0.26130258, 0.27577711), **unused):
+        self.image_mean, self.image_std = [float(v) for v in image_mean], [float(v) for v in image_std]
+
+    @classmethod
+    def from_json_file(cls, path: str) -> "CLIPFeatureExtractor":
+        import json
+        with open(path) as f:
+            cfg = json.load(f)
+        return cls(image_mean=cfg.get("image_mean", cls().image_mean), image_std=cfg.get("image_std", cls().image_std))
+
+    def __call__(self, images, do_normalize=True, do_center_crop=False, do_resize=False, do_rescale=False, return_tensors="pt", **unused):
+        if do_center_crop or do_resize or do_rescale:
+            raise NotImplementedError("the pipelines call the feature extractor with do_center_crop/do_resize/do_rescale=False")
+        x = images if torch.is_tensor(images) else torch.as_tensor(np.asarray(images))
+        x = x.float()
+        if do_normalize:
+            mean = torch.tensor(self.image_mean, dtype=x.dtype, device=x.device).view(1, -1, 1, 1)
+            std = torch.tensor(self.image_std, dtype=x.dtype, device=x.device).view(1, -1, 1, 1)
+            x = (x - mean) / std
+        return _PixelValues(pixel_values=x)
+
+
 class PipelineBase:
     """The sliver of diffusers.DiffusionPipeline the reference scripts touch."""
 

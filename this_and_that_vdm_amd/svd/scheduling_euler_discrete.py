@@ -44,6 +44,21 @@ class EulerDiscreteScheduler:
         self.num_inference_steps = None
         self._step_index = None
 
+    @classmethod
+    def from_config(cls, config) -> "EulerDiscreteScheduler":
+        """``config``: a dict or the path of a diffusers scheduler_config.json (e.g. <hub folder>/scheduler/).  Keys this
+        class does not take (``_class_name``, ``_diffusers_version``, ``trained_betas``: null, ``clip_sample`` ...) are
+        ignored; values it cannot honour raise in ``__init__``."""
+        if isinstance(config, str):
+            import json
+            with open(config) as f:
+                config = json.load(f)
+        import inspect
+        accepted = set(inspect.signature(cls.__init__).parameters) - {"self"}
+        if config.get("trained_betas") is not None:
+            raise NotImplementedError("trained_betas")
+        return cls(**{k: v for k, v in config.items() if k in accepted})
+
     @property
     def step_index(self):
         return self._step_index
