@@ -15,6 +15,10 @@
  *   - activations are token-major ("NHWC"): [frames*batch, h*w, C], C contiguous.
  *   - `dtype` selects the storage type of activations/weights: TT_BF16 or TT_F16; all
  *     accumulation, norm statistics, softmax and small vectors (bias, FiLM rows) are fp32.
+ *     TT_F32 is the reference-precision mode: the SAME kernels instantiated on fp32 storage with the
+ *     exact-fp32 matrix instruction (v_mfma_f32_32x32x2_f32, 1/16 of the bf16 rate).  It exists so the
+ *     whole launch sequence can be checked against the fp32 CPU reference at rtol 1e-3 / atol 1e-4
+ *     (16-bit operand rounding alone exceeds that); it is not the benchmarked path.
  */
 #ifndef TTVDM_H
 #define TTVDM_H
@@ -28,7 +32,7 @@ extern "C" {
 
 typedef void* tt_stream_t; /* hipStream_t */
 
-enum { TT_BF16 = 0, TT_F16 = 1 };
+enum { TT_BF16 = 0, TT_F16 = 1, TT_F32 = 2 };
 enum { TT_OK = 0, TT_EINVAL = -1, TT_EUNSUPPORTED = -2, TT_ELAUNCH = -3 };
 
 /* library/ABI version and target arch string ("gfx950"). */

@@ -15,15 +15,18 @@ def _inputs():
     return synthetic_inputs(2, 4, 8, 16, ctx_tokens=5, ctx_dim=64, seed=3)
 
 
+@pytest.mark.parametrize("dtype", [torch.float16, torch.float32])
 @pytest.mark.parametrize("with_cn", [True, False])
 @torch.no_grad()
-def test_fused_loop_matches_oracle_loop(with_cn):
+def test_fused_loop_matches_oracle_loop(with_cn, dtype):
+    """fp16 storage: relative L2 <= 3e-3; TT_F32 (reference-precision mode): every element of the final latents inside the
+    north-star tolerance rtol 1e-3 / atol 1e-4."""
     if not torch.cuda.is_available():
         pytest.skip("needs a GPU")
     from oracle.scheduler import EulerDiscreteScheduler as OSched, denoise_loop
+    from tests.parity_common import assert_north_star
     from this_and_that_vdm_amd.svd.denoise import DenoiseLoop
     from this_and_that_vdm_amd.svd.scheduling_euler_discrete import EulerDiscreteScheduler
-    dtype = torch.float16
     p_unet, p_cn, o_unet, o_cn = build_pair("tiny_vgl", dtype, "cuda:0", True)
     if not with_cn:
         p_cn = o_cn = None
@@ -48,8 +51,11 @@ def test_fused_loop_matches_oracle_loop(with_cn):
     torch.cuda.synchronize()
     assert torch.equal(split, outs[True]), "split-CFG branches must reproduce the joint launch"
     s = err_stats(outs[True], ref)
-    print("fused loop vs oracle loop:", s)
-    assert s["rel_l2"] <= 1e-2 and s["cos"] >= 0.9999, s
+    print(f"fused loop vs oracle loop ({dtype}):", s)
+    if dtype == torch.float32:
+        assert_north_star(outs[True].reshape(ref.shape), ref, "final latents of the 4-step fused loop (TT_F32)")
+    else:
+        assert s["rel_l2"] <= 3e-3 and s["cos"] >= 0.99999, s
     # second request on the same loop object re-uses the captured graph
     loop = DenoiseLoop(p_unet, p_cn, use_graph=True).begin(**kw)
     a = loop.run().clone()

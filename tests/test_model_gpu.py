@@ -1,17 +1,32 @@
 """GPU parity: drop-in UNet / GestureNet (HIP kernels through the C ABI) vs the CPU oracle and vs vectors the
 reference's own model files produced (tests/golden).
 
-Tolerance, stated: the north-star figure (rtol 1e-3 / atol 1e-4) is met per kernel on identical low-precision
-inputs (tests/test_ops_gpu.py, fp16).  End to end, every activation is stored in fp16 (2^-11) or bf16 (2^-8)
-through ~60 residual stages, so whole-model agreement is bounded by storage rounding: relative L2 error
-<= 1e-2 (fp16) / 5e-2 (bf16) and cosine >= 0.9999 / 0.999 are asserted here and the measured values printed."""
+Tolerance, stated (BASELINE.json north_star: rtol 1e-3 / atol 1e-4):
+  * TT_F32 (reference-precision mode: the same launch sequence, fp32 storage, exact-fp32 MFMA): every element of every
+    output inside rtol 1e-3 / atol 1e-4 -- ``torch.testing.assert_close`` -- against BOTH the oracle and the
+    reference-produced vectors.
+  * fp16 / bf16 storage (the benchmarked modes) cannot meet an ELEMENTWISE atol of 1e-4: rounding one MFMA operand to
+    fp16 (2^-11) already puts ~3e-4 relative noise on every GEMM output, an O(1e-4) absolute error wherever the reference
+    is near zero.  For them the measured fraction of elements inside the north-star tolerance is
+    printed and relative-L2 / cosine limits a few times above the measured values are asserted:
+    rel-L2 <= 3e-3 (fp16, measured 1.3e-3 .. 1.8e-3) / 2.5e-2 (bf16, measured 1.0e-2 .. 1.5e-2)."""
 import pytest
 import torch
 
 from tests.parity_common import run_tiny_vgl_parity
 
 pytestmark = pytest.mark.gpu
-LIMITS = {torch.float16: (1e-2, 0.9999), torch.bfloat16: (5e-2, 0.999)}
+LIMITS = {torch.float16: (3e-3, 0.99999), torch.bfloat16: (2.5e-2, 0.9995)}
+
+
+@pytest.mark.parametrize("name", ["tiny_vgl", "tiny_vl_d128"])
+def test_tiny_models_meet_the_north_star_tolerance_in_f32_mode(name):
+    if not torch.cuda.is_available():
+        pytest.skip("needs a GPU")
+    stats = run_tiny_vgl_parity(torch.float32, "cuda:0", name, strict=True)        # asserts elementwise inside
+    for k, s in stats.items():
+        print(f"{name} TT_F32 {k}: {s}")
+        assert s["frac_in_tol"] == 1.0 and s["rel_l2"] <= 1e-4, (k, s)
 
 
 @pytest.mark.parametrize("dtype", [torch.float16, torch.bfloat16])
@@ -22,6 +37,6 @@ def test_tiny_models_match_oracle_and_reference_vectors(name, dtype):
     stats = run_tiny_vgl_parity(dtype, "cuda:0", name)
     rel, cos = LIMITS[dtype]
     for k, s in stats.items():
-        print(f"{name} {dtype} {k}: {s}")
+        print(f"{name} {dtype} {k}: {s}   [fraction of elements inside rtol 1e-3 / atol 1e-4: {s['frac_in_tol']:.4f}]")
     for k, s in stats.items():
         assert s["rel_l2"] <= rel and s["cos"] >= cos, (k, s)

@@ -1,6 +1,8 @@
 """GPU: every libttvdm kernel (called through the C ABI) against a plain PyTorch fp32 reference of the
-same op evaluated on the SAME low-precision inputs.  Tolerances (stated per test): outputs are rounded
-to fp16 (2^-11 rel) / bf16 (2^-8 rel) on store, accumulation is fp32."""
+same op evaluated on the SAME inputs, in all three storage modes.  Tolerances:
+  fp16   rtol = atol = 1e-3   (north_star's rtol; outputs are rounded to fp16, 2^-11, on store; accumulation is fp32)
+  bf16   rtol = atol = 1.6e-2 (2^-8 on store; `scale` widens atol where the outputs are O(4))
+  fp32   rtol = atol = 2e-5   (TT_F32, the reference-precision mode: exact-fp32 MFMA, only the summation order differs)"""
 import math
 
 import pytest
@@ -9,8 +11,10 @@ import torch.nn.functional as F
 
 pytestmark = pytest.mark.gpu
 
-DTYPES = [torch.float16, torch.bfloat16]
-TOL = {torch.float16: dict(rtol=2e-3, atol=2e-3), torch.bfloat16: dict(rtol=1.6e-2, atol=1.6e-2)}
+DTYPES16 = [torch.float16, torch.bfloat16]
+DTYPES = DTYPES16 + [torch.float32]
+TOL = {torch.float16: dict(rtol=1e-3, atol=1e-3), torch.bfloat16: dict(rtol=1.6e-2, atol=1.6e-2),
+       torch.float32: dict(rtol=2e-5, atol=2e-5)}
 
 
 @pytest.fixture(scope="module")
@@ -28,7 +32,8 @@ def rnd(*shape, dtype, seed, scale=1.0):
 
 def close(got, ref, dtype, scale=1.0):
     tol = TOL[dtype]
-    torch.testing.assert_close(got.float().cpu(), ref.float(), rtol=tol["rtol"], atol=tol["atol"] * scale)
+    torch.testing.assert_close(got.float().cpu(), ref.float(), rtol=tol["rtol"],
+                               atol=tol["atol"] * (scale if dtype == torch.bfloat16 else 1.0))
 
 
 @pytest.mark.parametrize("dtype", DTYPES)
@@ -317,7 +322,7 @@ def test_errors_are_loud(ops):
         ops.gemm(torch.zeros(8, 16, dtype=torch.float16), torch.zeros(8, 16, dtype=torch.float16))
 
 
-@pytest.mark.parametrize("cfg", list(range(26)))
+@pytest.mark.parametrize("cfg", list(range(17)))
 def test_gemm_every_tile_configuration(ops, cfg):
     """each entry of the tile table in gemm.hip, forced, on a ragged linear and a 2-source conv (bf16)."""
     from this_and_that_vdm_amd import _lib
@@ -343,7 +348,7 @@ def test_gemm_every_tile_configuration(ops, cfg):
         lib.tt_gemm_set_tile_override(-1)
 
 
-@pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("dtype", DTYPES16)
 @pytest.mark.parametrize("m", [4101, 50176, 3 * 8192 - 31])
 @pytest.mark.parametrize("epi", ["plain", "bias_res", "blend"])
 def test_gemm_square_320_streaming_kernel(ops, dtype, m, epi):
@@ -409,7 +414,7 @@ def test_gemm_tall_short_k(ops, n, rowvec):
 
 
 @pytest.mark.parametrize("m,n,k,cfg", [(12544, 640, 640, -1), (3136, 1280, 1280, -1), (12544, 2560, 320, -1), (50176, 320, 320, -1),
-                                       (3136, 1280, 640, 1), (1500, 640, 1280, 2), (8192, 1024, 512, 21), (4096, 640, 512, 23)])
+                                       (3136, 1280, 640, 1), (1500, 640, 1280, 2), (8192, 1024, 512, 13), (4096, 640, 512, 14)])
 def test_gemm_is_repeatable_under_load(ops, m, n, k, cfg):
     """the K loop reads LDS with instructions the compiler cannot see and orders them against the LDS-DMA by counted
     waits and barriers only: a misplaced wait would show up as run-to-run differences.  40 launches back to back

@@ -10,7 +10,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(_HERE, "csrc")
 LIB_PATH = os.path.join(CSRC, "libttvdm.so")
 
-TT_BF16, TT_F16 = 0, 1
+TT_BF16, TT_F16, TT_F32 = 0, 1, 2
 
 
 class TtGemmArgs(C.Structure):

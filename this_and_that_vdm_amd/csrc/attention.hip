@@ -35,13 +35,17 @@ __device__ __forceinline__ float fast_exp2(float x) { return __builtin_amdgcn_ex
 template <typename Tag, int D, int MASK>
 __global__ __launch_bounds__(256) void attn_kernel(const AttnP p) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
-  constexpr int KCPR = D / 8;                 // 16-B chunks per K-tile row (row = key, D elements)
-  constexpr int K_BYTES = KB * D * 2;
-  constexpr int V_BYTES = D * KB * 2;         // rows = d (D rows), 64 keys = 128 B per row
+  typedef typename Elem<Tag>::quad_t quad_t;
+  constexpr int ES = Elem<Tag>::ES, EPC = Elem<Tag>::EPC;   // bytes per element, elements per 16-byte chunk
+  constexpr int KCPR = D / EPC;               // 16-B chunks per K-tile row (row = key, D elements)
+  constexpr int VCPR = KB / EPC;              // 16-B chunks per V^T-tile row (row = d, 64 keys)
+  constexpr int K_BYTES = KB * D * ES;
+  constexpr int V_BYTES = D * KB * ES;        // rows = d (D rows), 64 keys per row
   constexpr int STAGE = K_BYTES + V_BYTES;
   constexpr int KPT = (KB * KCPR) / 256;      // K chunks per thread
-  constexpr int VPT = (D * 8) / 256;          // Vt chunks per thread
-  constexpr int DS = D / 16, DB = D / 32;
+  constexpr int VPT = (D * VCPR) / 256;       // Vt chunks per thread
+  constexpr int DS = KCPR / 2, DB = D / 32;   // operand reads per K row (one chunk per lane half), 32-wide d blocks
+  constexpr int PH = 16 / EPC;                // P chunks per lane per 32-key block
 
   const int tid = threadIdx.x, lane = tid & 63;
   const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -71,9 +75,9 @@ __global__ __launch_bounds__(256) void attn_kernel(const AttnP p) {
   const bool qok = qrow < p.lq;
   uint4 qf[DS];
   {
-    const char* qp = p.q + (((long)seq * p.lq + (qok ? qrow : 0)) * p.ldq + head * D) * 2;
+    const char* qp = p.q + (((long)seq * p.lq + (qok ? qrow : 0)) * p.ldq + head * D) * ES;
 #pragma unroll
-    for (int ds = 0; ds < DS; ++ds) qf[ds] = qok ? *(const uint4*)(qp + (ds * 16 + hi * 8) * 2) : make_uint4(0, 0, 0, 0);
+    for (int ds = 0; ds < DS; ++ds) qf[ds] = qok ? *(const uint4*)(qp + (ds * 2 + hi) * 16) : make_uint4(0, 0, 0, 0);
   }
 
   // staging by buffer_load ... lds: per-lane 32-bit byte offsets computed once, the tile position is a scalar offset,
@@ -87,14 +91,14 @@ __global__ __launch_bounds__(256) void attn_kernel(const AttnP p) {
     const int slot = i * 256 + tid;
     const int r = slot / KCPR, c = (slot % KCPR) ^ tile_swz<KCPR>(r);
     kr[i] = r;
-    kvo[i] = (int)((((long)kbase + r) * p.ldk + head * D + c * 8) * 2);
+    kvo[i] = (int)((((long)kbase + r) * p.ldk + head * D + c * EPC) * ES);
   }
 #pragma unroll
   for (int i = 0; i < VPT; ++i) {
     const int slot = i * 256 + tid;
-    const int r = slot >> 3, c = (slot & 7) ^ tile_swz<8>(r);
-    vc[i] = c * 8;
-    vvo[i] = (int)(((long)(head * D + r) * p.ldvt + vbase + c * 8) * 2);
+    const int r = slot / VCPR, c = (slot % VCPR) ^ tile_swz<VCPR>(r);
+    vc[i] = c * EPC;
+    vvo[i] = (int)(((long)(head * D + r) * p.ldvt + vbase + c * EPC) * ES);
   }
   const int k_rows_left = p.k_rows_total - kbase;            // rows of K that exist from kbase on
   const long v_cols_left = p.vt_cols_total - vbase;
@@ -102,8 +106,8 @@ __global__ __launch_bounds__(256) void attn_kernel(const AttnP p) {
     const int j0 = tile * KB;
     char* lk_ = smem + buf * STAGE + wid * 1024;
     char* lv_ = smem + buf * STAGE + K_BYTES + wid * 1024;
-    const int soff_k = __builtin_amdgcn_readfirstlane((int)((long)j0 * p.ldk * 2));
-    const int soff_v = j0 * 2;
+    const int soff_k = __builtin_amdgcn_readfirstlane((int)((long)j0 * p.ldk * ES));
+    const int soff_v = j0 * ES;
     const bool edge = j0 + KB > k_rows_left || j0 + KB > v_cols_left;    // uniform: only the last tile(s)
 #pragma unroll
     for (int i = 0; i < KPT; ++i) {
@@ -172,15 +176,15 @@ __global__ __launch_bounds__(256) void attn_kernel(const AttnP p) {
     const float alpha = fast_exp2(m_run - m_new);
     m_run = m_new;
     float psum = 0.f;
-    uint4 pf[4];
+    uint4 pf[2][PH];
 #pragma unroll
     for (int kb = 0; kb < 2; ++kb)
 #pragma unroll
-      for (int h = 0; h < 2; ++h) {
-        float e[8];
+      for (int h = 0; h < PH; ++h) {
+        float e[EPC];
 #pragma unroll
-        for (int r = 0; r < 8; ++r) { e[r] = fast_exp2(fmaf(s[kb][h * 8 + r], p.scale_log2e, -m_new)); psum += e[r]; }
-        pf[kb * 2 + h] = pack8<Tag>(e);
+        for (int r = 0; r < EPC; ++r) { e[r] = fast_exp2(fmaf(s[kb][h * EPC + r], p.scale_log2e, -m_new)); psum += e[r]; }
+        pf[kb][h] = pack_chunk<Tag>(e);
       }
     l_run = l_run * alpha + psum;
     if (__any(alpha != 1.0f)) {                                 // the running max moved for some query of this wave
@@ -189,16 +193,18 @@ __global__ __launch_bounds__(256) void attn_kernel(const AttnP p) {
 #pragma unroll
         for (int r = 0; r < 16; ++r) o[i][r] *= alpha;
     }
-    // ---- O^T += Vt_tile * P^T : k-slot (hi, e) of step (kb,h) is key kb*32 + 16*hi + 8*h + e
+    // ---- O^T += Vt_tile * P^T : k-slot (hi, e) of step (kb,h) is key kb*32 + 16*hi + EPC*h + e
 #pragma unroll
     for (int db = 0; db < DB; ++db) {
       const int row = db * 32 + l31;
 #pragma unroll
-      for (int kk = 0; kk < 4; ++kk) {
-        const int chunk = (kk >> 1) * 4 + 2 * hi + (kk & 1);
-        const uint4 vf = lds_read16(sv, tile_off<8>(row, chunk));
-        o[db] = Cvt<Tag>::mfma32(vf, pf[kk], o[db]);
-      }
+      for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+        for (int h = 0; h < PH; ++h) {
+          const int chunk = kb * (32 / EPC) + hi * PH + h;
+          const uint4 vf = lds_read16(sv, tile_off<VCPR>(row, chunk));
+          o[db] = Cvt<Tag>::mfma32(vf, pf[kb][h], o[db]);
+        }
     }
   }
   // ---- finalize: lane holds query l31, d = db*32 + 8g + 4hi + {0..3}.  Stored directly an instruction would write 16
@@ -207,16 +213,16 @@ __global__ __launch_bounds__(256) void attn_kernel(const AttnP p) {
   float l_tot = l_run + __shfl_xor(l_run, 32);
   const float inv = l_tot > 0.f ? 1.0f / l_tot : 0.f;
   __syncthreads();                                     // every wave is done with the K / V tiles
-  constexpr int ROWB_O = D * 2, CPR_O = ROWB_O / 16;   // output row bytes per head, 16-byte chunks per row
+  constexpr int ROWB_O = D * ES, CPR_O = ROWB_O / 16;  // output row bytes per head, 16-byte chunks per row
   char* strip = smem + wid * (32 * ROWB_O);
   static_assert(4 * 32 * ROWB_O <= 2 * STAGE, "output strips do not fit the K/V ring");
 #pragma unroll
   for (int db = 0; db < DB; ++db)
 #pragma unroll
     for (int g = 0; g < 4; ++g) {
-      const int chunk = db * 4 + g;                    // 16-byte chunk of d = chunk*8 .. +8; this lane owns half hi
-      *(uint2*)(strip + l31 * ROWB_O + ((chunk ^ (l31 & (CPR_O - 1))) << 4) + hi * 8) =
-          make_uint2(pack2<Tag>(o[db][g * 4] * inv, o[db][g * 4 + 1] * inv), pack2<Tag>(o[db][g * 4 + 2] * inv, o[db][g * 4 + 3] * inv));
+      const int byte = (db * 32 + 8 * g + 4 * hi) * ES;   // this lane's 4 consecutive d of query row l31
+      const float v4[4] = {o[db][g * 4] * inv, o[db][g * 4 + 1] * inv, o[db][g * 4 + 2] * inv, o[db][g * 4 + 3] * inv};
+      *(quad_t*)(strip + l31 * ROWB_O + (((byte >> 4) ^ (l31 & (CPR_O - 1))) << 4) + (byte & 15)) = f32_to_quad<Tag>(v4);
     }
   constexpr int RPP = 64 / CPR_O;                      // rows per pass
   const int oc = lane % CPR_O, orow = lane / CPR_O;
@@ -225,13 +231,14 @@ __global__ __launch_bounds__(256) void attn_kernel(const AttnP p) {
     const int r = pass * RPP + orow;
     const uint4 v = *(const uint4*)(strip + r * ROWB_O + ((oc ^ (r & (CPR_O - 1))) << 4));
     const int qr = (qblk * QB + wid * 32 + r) * qstride + qcls;
-    if (qr < p.lq) *(uint4*)(p.out + (((long)seq * p.lq + qr) * p.ldo + head * D) * 2 + oc * 16) = v;
+    if (qr < p.lq) *(uint4*)(p.out + (((long)seq * p.lq + qr) * p.ldo + head * D) * ES + oc * 16) = v;
   }
 }
 
 template <typename Tag, int D, int MASK>
 void launch_attn_m(const AttnP& p, hipStream_t st) {
-  constexpr size_t lds = 2 * (KB * D * 2 + D * KB * 2);
+  constexpr size_t lds = 2 * (KB * D * Elem<Tag>::ES + D * KB * Elem<Tag>::ES);
+  static_assert(lds <= 160 * 1024, "attention K/V ring exceeds the LDS");
   static unsigned long long attr_done = 0;
   tt_lds_opt_in((const void*)attn_kernel<Tag, D, MASK>, (int)lds, &attr_done);
   // mask 2: one block per (query residue class, QB queries of that class)
@@ -250,7 +257,7 @@ void launch_attn(const AttnP& p, hipStream_t st) {
 // temporal kernel need neither operand unpacked
 typedef __attribute__((ext_vector_type(2))) _Float16 tt_half2;
 typedef __attribute__((ext_vector_type(2))) __bf16 tt_bf162;
-template <typename Tag> __device__ __forceinline__ float dot2_acc(unsigned a, unsigned b, float acc);
+template <typename Tag> __device__ __forceinline__ float dot2_acc(unsigned a, unsigned b, float acc) { return acc; }   // f32_tag never calls it
 template <> __device__ __forceinline__ float dot2_acc<bf16_tag>(unsigned a, unsigned b, float acc) {
   return __builtin_amdgcn_fdot2_f32_bf16(__builtin_bit_cast(tt_bf162, a), __builtin_bit_cast(tt_bf162, b), acc, false);
 }
@@ -265,8 +272,10 @@ template <typename Tag, int D, int LPU>
 __global__ __launch_bounds__(128) void tattn_kernel(const char* qkv, long ldqkv, char* out, long ldo, int batch,
                                                     int frames, int hw, int heads, float scale_log2e) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
+  constexpr int ES = Elem<Tag>::ES, EPC = Elem<Tag>::EPC;
+  constexpr bool F32 = ES == 4;
   constexpr int UPB = 128 / LPU;                 // units per block
-  constexpr int ROWB = D * 2 + 16;               // padded row bytes
+  constexpr int ROWB = D * ES + 16;              // padded row bytes
   constexpr int UNITB = LPU * ROWB + 64;         // unit stride: the 4 units a wave touches sit 16 banks apart
   const int C = heads * D;
   const int tid = threadIdx.x;
@@ -281,14 +290,14 @@ __global__ __launch_bounds__(128) void tattn_kernel(const char* qkv, long ldqkv,
   const int pix = (int)(bp % hw);
   const int b = (int)(bp / hw);
   const long qrow = ((long)b * frames + fi) * hw + pix;
-  uint4 qv[D / 8];           // the query row stays packed: scores are 16-bit dot2 products accumulated in fp32
+  uint4 qv[D / EPC];         // the query row stays packed: 16-bit scores are dot2 products accumulated in fp32
   if (active) {
-    const char* qp = qkv + (qrow * ldqkv + h * D) * 2;
+    const char* qp = qkv + (qrow * ldqkv + h * D) * ES;
 #pragma unroll
-    for (int c = 0; c < D / 8; ++c) qv[c] = *(const uint4*)(qp + c * 16);
+    for (int c = 0; c < D / EPC; ++c) qv[c] = *(const uint4*)(qp + c * 16);
   }
   // stage K and V rows: unit u, frame f
-  const int chunks_per_row = D / 8;
+  const int chunks_per_row = D / EPC;
   const int nchunks = UPB * frames * chunks_per_row;
   for (int tensor = 0; tensor < 2; ++tensor) {
     char* dst = smem + tensor * (UPB * UNITB);
@@ -303,7 +312,7 @@ __global__ __launch_bounds__(128) void tattn_kernel(const char* qkv, long ldqkv,
         const int spix = (int)(sbp % hw);
         const int sb = (int)(sbp / hw);
         const long row = ((long)sb * frames + f) * hw + spix;
-        v = *(const uint4*)(qkv + (row * ldqkv + (tensor + 1) * C + sh * D + c * 8) * 2);
+        v = *(const uint4*)(qkv + (row * ldqkv + (tensor + 1) * C + sh * D + c * EPC) * ES);
       }
       *(uint4*)(dst + ul * UNITB + f * ROWB + c * 16) = v;
     }
@@ -320,12 +329,19 @@ __global__ __launch_bounds__(128) void tattn_kernel(const char* qkv, long ldqkv,
     if (j < frames) {
       float a1 = 0.f;        // two accumulation chains
 #pragma unroll
-      for (int c = 0; c < D / 8; ++c) {
+      for (int c = 0; c < D / EPC; ++c) {
         const uint4 kv = *(const uint4*)(ks + j * ROWB + c * 16);
-        a = dot2_acc<Tag>(qv[c].x, kv.x, a);
-        a1 = dot2_acc<Tag>(qv[c].y, kv.y, a1);
-        a = dot2_acc<Tag>(qv[c].z, kv.z, a);
-        a1 = dot2_acc<Tag>(qv[c].w, kv.w, a1);
+        if constexpr (F32) {
+          a = fmaf(__uint_as_float(qv[c].x), __uint_as_float(kv.x), a);
+          a1 = fmaf(__uint_as_float(qv[c].y), __uint_as_float(kv.y), a1);
+          a = fmaf(__uint_as_float(qv[c].z), __uint_as_float(kv.z), a);
+          a1 = fmaf(__uint_as_float(qv[c].w), __uint_as_float(kv.w), a1);
+        } else {
+          a = dot2_acc<Tag>(qv[c].x, kv.x, a);
+          a1 = dot2_acc<Tag>(qv[c].y, kv.y, a1);
+          a = dot2_acc<Tag>(qv[c].z, kv.z, a);
+          a1 = dot2_acc<Tag>(qv[c].w, kv.w, a1);
+        }
       }
       a = (a + a1) * scale_log2e;
       mx = fmaxf(mx, a);
@@ -344,23 +360,24 @@ __global__ __launch_bounds__(128) void tattn_kernel(const char* qkv, long ldqkv,
     if (j < frames) {
       const float pj = sc[j] * inv;
 #pragma unroll
-      for (int c = 0; c < D / 8; ++c) {
-        float vf[8];
-        unpack8<Tag>(*(const uint4*)(vs + j * ROWB + c * 16), vf);
+      for (int c = 0; c < D / EPC; ++c) {
+        float vf[EPC];
+        unpack_chunk<Tag>(*(const uint4*)(vs + j * ROWB + c * 16), vf);
 #pragma unroll
-        for (int e = 0; e < 8; ++e) acc[c * 8 + e] = fmaf(pj, vf[e], acc[c * 8 + e]);
+        for (int e = 0; e < EPC; ++e) acc[c * EPC + e] = fmaf(pj, vf[e], acc[c * EPC + e]);
       }
     }
   }
-  char* op = out + (qrow * ldo + h * D) * 2;
+  char* op = out + (qrow * ldo + h * D) * ES;
 #pragma unroll
-  for (int c = 0; c < D / 8; ++c) *(uint4*)(op + c * 16) = pack8<Tag>(acc + c * 8);
+  for (int c = 0; c < D / EPC; ++c) *(uint4*)(op + c * 16) = pack_chunk<Tag>(acc + c * EPC);
 }
 
 template <typename Tag, int D, int LPU>
 void launch_tattn(const void* qkv, long ldqkv, void* out, long ldo, int batch, int frames, int hw, int heads, hipStream_t st) {
   constexpr int UPB = 128 / LPU;
-  constexpr size_t lds = 2 * UPB * (LPU * (D * 2 + 16) + 64);
+  constexpr size_t lds = 2 * UPB * (LPU * (D * Elem<Tag>::ES + 16) + 64);
+  static_assert(lds <= 160 * 1024, "temporal attention staging exceeds the LDS");
   static unsigned long long attr_done = 0;
   tt_lds_opt_in((const void*)tattn_kernel<Tag, D, LPU>, (int)lds, &attr_done);
   const long units = (long)batch * hw * heads;
@@ -376,13 +393,14 @@ extern "C" int tt_attention(const TtAttnArgs* a, tt_stream_t stream) {
   if (a->head_dim != 64 && a->head_dim != 128) TT_FAIL(TT_EUNSUPPORTED, "tt_attention: head_dim %d (64 or 128)", a->head_dim);
   if (a->nseq <= 0 || a->lq <= 0 || a->heads <= 0 || a->lk <= 0) TT_FAIL(TT_EINVAL, "tt_attention: empty problem");
   if (a->mask < 0 || a->mask > 2) TT_FAIL(TT_EINVAL, "tt_attention: mask %d", a->mask);
-  if ((a->ldq & 7) || (a->ldk & 7) || (a->ldvt & 7) || (a->ldo & 7) || (a->v_seq_stride & 7))
-    TT_FAIL(TT_EINVAL, "tt_attention: strides must keep 16-byte chunks aligned");
   if (a->mask != 0 && (a->frames <= 0 || a->ctx_batches <= 0 || a->nseq % a->frames)) TT_FAIL(TT_EINVAL, "tt_attention: frames/ctx");
   if (a->mask != 0 && (a->batch0 < 0 || a->batch0 + a->nseq / a->frames > a->ctx_batches)) TT_FAIL(TT_EINVAL, "tt_attention: batch0 + batches exceeds ctx_batches");
   if (a->lk > a->k_seq_stride || a->lk > a->v_seq_stride) TT_FAIL(TT_EINVAL, "tt_attention: lk exceeds sequence stride");
   if (a->mask == 2 && a->k_seq_stride != a->v_seq_stride) TT_FAIL(TT_EINVAL, "tt_attention: mask 2 needs equal k/v context strides");
-  if (a->dtype != TT_BF16 && a->dtype != TT_F16) TT_FAIL(TT_EINVAL, "tt_attention: bad dtype");
+  if (a->dtype != TT_BF16 && a->dtype != TT_F16 && a->dtype != TT_F32) TT_FAIL(TT_EINVAL, "tt_attention: bad dtype");
+  const int es = a->dtype == TT_F32 ? 4 : 2;
+  if (((a->ldq * es) & 15) || ((a->ldk * es) & 15) || ((a->ldvt * es) & 15) || ((a->ldo * es) & 15) || ((a->v_seq_stride * es) & 15))
+    TT_FAIL(TT_EINVAL, "tt_attention: strides must keep 16-byte chunks aligned");
   AttnP p;
   p.q = (const char*)a->q; p.ldq = a->ldq; p.k = (const char*)a->k; p.ldk = a->ldk;
   p.vt = (const char*)a->vt; p.ldvt = a->ldvt; p.out = (char*)a->out; p.ldo = a->ldo;
@@ -393,15 +411,16 @@ extern "C" int tt_attention(const TtAttnArgs* a, tt_stream_t stream) {
   p.vt_cols_total = (long)nctx * a->v_seq_stride;
   if (p.vt_cols_total > a->ldvt) TT_FAIL(TT_EINVAL, "tt_attention: ldvt smaller than the key columns");
   {
-    const long kb = ((long)(p.k_rows_total - 1) * a->ldk + (long)a->heads * a->head_dim) * 2;
-    const long vb = ((long)(a->heads * a->head_dim - 1) * a->ldvt + p.vt_cols_total) * 2;
+    const long kb = ((long)(p.k_rows_total - 1) * a->ldk + (long)a->heads * a->head_dim) * es;
+    const long vb = ((long)(a->heads * a->head_dim - 1) * a->ldvt + p.vt_cols_total) * es;
     if (kb >= (1L << 31) || vb >= (1L << 31)) TT_FAIL(TT_EUNSUPPORTED, "tt_attention: K or V^T larger than 2 GiB");
     p.k_bytes = (unsigned)kb; p.vt_bytes = (unsigned)vb;
   }
   p.scale_log2e = 1.4426950408889634f / sqrtf((float)a->head_dim);
   hipStream_t st = (hipStream_t)stream;
   if (a->dtype == TT_BF16) { if (a->head_dim == 64) launch_attn<bf16_tag, 64>(p, st); else launch_attn<bf16_tag, 128>(p, st); }
-  else { if (a->head_dim == 64) launch_attn<f16_tag, 64>(p, st); else launch_attn<f16_tag, 128>(p, st); }
+  else if (a->dtype == TT_F16) { if (a->head_dim == 64) launch_attn<f16_tag, 64>(p, st); else launch_attn<f16_tag, 128>(p, st); }
+  else { if (a->head_dim == 64) launch_attn<f32_tag, 64>(p, st); else launch_attn<f32_tag, 128>(p, st); }
   TT_CHECK_LAUNCH("tt_attention");
   return TT_OK;
 }
@@ -411,16 +430,19 @@ extern "C" int tt_temporal_attention(const void* qkv, int64_t ldqkv, void* out, 
   if (!qkv || !out) TT_FAIL(TT_EINVAL, "tt_temporal_attention: null operand");
   if (head_dim != 64 && head_dim != 128) TT_FAIL(TT_EUNSUPPORTED, "tt_temporal_attention: head_dim %d", head_dim);
   if (frames <= 0 || frames > 32) TT_FAIL(TT_EUNSUPPORTED, "tt_temporal_attention: frames %d (1..32)", frames);
-  if ((ldqkv & 7) || (ldo & 7)) TT_FAIL(TT_EINVAL, "tt_temporal_attention: strides");
-  if (dtype != TT_BF16 && dtype != TT_F16) TT_FAIL(TT_EINVAL, "tt_temporal_attention: bad dtype");
+  if (dtype != TT_BF16 && dtype != TT_F16 && dtype != TT_F32) TT_FAIL(TT_EINVAL, "tt_temporal_attention: bad dtype");
+  if (((ldqkv * (dtype == TT_F32 ? 4 : 2)) & 15) || ((ldo * (dtype == TT_F32 ? 4 : 2)) & 15)) TT_FAIL(TT_EINVAL, "tt_temporal_attention: strides");
   hipStream_t st = (hipStream_t)stream;
 #define TT_TA(TAG, D, L) launch_tattn<TAG, D, L>(qkv, ldqkv, out, ldo, batch, frames, hw, heads, st)
   if (dtype == TT_BF16) {
     if (head_dim == 64) { if (frames <= 16) TT_TA(bf16_tag, 64, 16); else TT_TA(bf16_tag, 64, 32); }
     else { if (frames <= 16) TT_TA(bf16_tag, 128, 16); else TT_TA(bf16_tag, 128, 32); }
-  } else {
+  } else if (dtype == TT_F16) {
     if (head_dim == 64) { if (frames <= 16) TT_TA(f16_tag, 64, 16); else TT_TA(f16_tag, 64, 32); }
     else { if (frames <= 16) TT_TA(f16_tag, 128, 16); else TT_TA(f16_tag, 128, 32); }
+  } else {
+    if (head_dim == 64) { if (frames <= 16) TT_TA(f32_tag, 64, 16); else TT_TA(f32_tag, 64, 32); }
+    else { if (frames <= 16) TT_TA(f32_tag, 128, 16); else TT_TA(f32_tag, 128, 32); }
   }
 #undef TT_TA
   TT_CHECK_LAUNCH("tt_temporal_attention");

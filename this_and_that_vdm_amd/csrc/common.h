@@ -14,6 +14,12 @@ typedef __attribute__((ext_vector_type(4))) float f32x4_t;
 
 struct bf16_tag {};
 struct f16_tag {};
+struct f32_tag {};     // reference-precision mode (TT_F32): fp32 storage, exact-fp32 MFMA (v_mfma_f32_32x32x2_f32)
+
+// storage geometry of a tag: bytes per element, elements per 16-byte chunk (the unit of LDS-DMA staging and of one
+// MFMA operand read), and the register type holding 4 consecutive elements
+template <typename Tag> struct Elem { static constexpr int ES = 2, EPC = 8; typedef uint2 quad_t; };
+template <> struct Elem<f32_tag> { static constexpr int ES = 4, EPC = 4; typedef uint4 quad_t; };
 
 // 16 zero bytes (x4 for safety) that out-of-range tile lanes point their global source at.
 static __device__ __attribute__((aligned(64))) unsigned int tt_zero_page[64] = {0};   // per-TU copy: no -fgpu-rdc needed
@@ -55,6 +61,18 @@ template <> struct Cvt<f16_tag> {
   }
 };
 
+// fp32 "conversion" is the identity; one 16-byte chunk holds 4 k-values, consumed by 4 exact-fp32 MFMAs (K = 2 each:
+// lane (l31, hi) supplies k-slot hi).  Bitwise an fmaf chain in k order (MI355X guide, f32-input MFMA).
+template <> struct Cvt<f32_tag> {
+  static __device__ __forceinline__ f32x16_t mfma32(uint4 a, uint4 b, f32x16_t c) {
+    c = __builtin_amdgcn_mfma_f32_32x32x2f32(__uint_as_float(a.x), __uint_as_float(b.x), c, 0, 0, 0);
+    c = __builtin_amdgcn_mfma_f32_32x32x2f32(__uint_as_float(a.y), __uint_as_float(b.y), c, 0, 0, 0);
+    c = __builtin_amdgcn_mfma_f32_32x32x2f32(__uint_as_float(a.z), __uint_as_float(b.z), c, 0, 0, 0);
+    c = __builtin_amdgcn_mfma_f32_32x32x2f32(__uint_as_float(a.w), __uint_as_float(b.w), c, 0, 0, 0);
+    return c;
+  }
+};
+
 // two floats -> one dword of two 16-bit values, one instruction (v_cvt_pk_bf16_f32 / v_cvt_pk_f16_f32, RNE)
 typedef __attribute__((ext_vector_type(2))) float f32x2_t;
 typedef __attribute__((ext_vector_type(2))) __bf16 bf16x2_t;
@@ -84,6 +102,41 @@ template <typename Tag> __device__ __forceinline__ void unpack4(const uint2& v, 
   f[3] = Cvt<Tag>::to_f32((unsigned short)(v.y >> 16));
 }
 
+// ---- tag-generic element access (16-bit tags: packed halves; f32_tag: plain floats)
+template <typename Tag> __device__ __forceinline__ void quad_to_f32(const typename Elem<Tag>::quad_t& q, float* f) { unpack4<Tag>(q, f); }
+template <> __device__ __forceinline__ void quad_to_f32<f32_tag>(const uint4& q, float* f) {
+  f[0] = __uint_as_float(q.x); f[1] = __uint_as_float(q.y); f[2] = __uint_as_float(q.z); f[3] = __uint_as_float(q.w);
+}
+template <typename Tag> __device__ __forceinline__ typename Elem<Tag>::quad_t f32_to_quad(const float* f) {
+  return make_uint2(pack2<Tag>(f[0], f[1]), pack2<Tag>(f[2], f[3]));
+}
+template <> __device__ __forceinline__ uint4 f32_to_quad<f32_tag>(const float* f) {
+  return make_uint4(__float_as_uint(f[0]), __float_as_uint(f[1]), __float_as_uint(f[2]), __float_as_uint(f[3]));
+}
+// one 16-byte chunk (EPC elements) <-> floats
+template <typename Tag> __device__ __forceinline__ uint4 pack_chunk(const float* f) { return pack8<Tag>(f); }
+template <> __device__ __forceinline__ uint4 pack_chunk<f32_tag>(const float* f) { return f32_to_quad<f32_tag>(f); }
+template <typename Tag> __device__ __forceinline__ void unpack_chunk(const uint4& v, float* f) { unpack8<Tag>(v, f); }
+template <> __device__ __forceinline__ void unpack_chunk<f32_tag>(const uint4& v, float* f) { quad_to_f32<f32_tag>(v, f); }
+// 8 consecutive elements at byte address p (16-byte aligned)
+template <typename Tag> __device__ __forceinline__ void load8(const char* p, float* f) { unpack8<Tag>(*(const uint4*)p, f); }
+template <> __device__ __forceinline__ void load8<f32_tag>(const char* p, float* f) {
+  const float4 a = *(const float4*)p, b = *(const float4*)(p + 16);
+  f[0] = a.x; f[1] = a.y; f[2] = a.z; f[3] = a.w; f[4] = b.x; f[5] = b.y; f[6] = b.z; f[7] = b.w;
+}
+template <typename Tag> __device__ __forceinline__ void store8(char* p, const float* f) { *(uint4*)p = pack8<Tag>(f); }
+template <> __device__ __forceinline__ void store8<f32_tag>(char* p, const float* f) {
+  *(float4*)p = make_float4(f[0], f[1], f[2], f[3]);
+  *(float4*)(p + 16) = make_float4(f[4], f[5], f[6], f[7]);
+}
+template <typename Tag> __device__ __forceinline__ float load1(const char* p) { return Cvt<Tag>::to_f32(*(const unsigned short*)p); }
+template <> __device__ __forceinline__ float load1<f32_tag>(const char* p) { return *(const float*)p; }
+template <typename Tag> __device__ __forceinline__ void store1(char* p, float v) { *(unsigned short*)p = Cvt<Tag>::from_f32(v); }
+template <> __device__ __forceinline__ void store1<f32_tag>(char* p, float v) { *(float*)p = v; }
+// the value a store of v followed by a load would return (storage rounding; identity for fp32)
+template <typename Tag> __device__ __forceinline__ float round_store(float v) { return Cvt<Tag>::to_f32(Cvt<Tag>::from_f32(v)); }
+template <> __device__ __forceinline__ float round_store<f32_tag>(float v) { return v; }
+
 __device__ __forceinline__ float silu_f(float x) { return x / (1.0f + __expf(-x)); }
 // exact-erf GELU with erf from Abramowitz-Stegun 7.1.26 (|error| <= 1.5e-7, far below fp16/bf16 output rounding):
 // ~14 VALU ops instead of libm erff's ~40 -- the GEGLU epilogue evaluates it 4C times per token.
@@ -105,7 +158,7 @@ __device__ __forceinline__ float gelu_erf_f(float x) {
 // group touches over all 16 slots of the 256-B bank row (cdna guide section 6, guideline 4).
 template <int CPR> __device__ __forceinline__ int tile_swz(int row) {
   if constexpr (CPR == 8) return (row >> 1) & 7;        // 128-B rows: two rows per bank row
-  else if constexpr (CPR == 16) return row & 15;        // 256-B rows
+  else if constexpr (CPR == 16 || CPR == 32) return row & 15;   // 256-B / 512-B rows (the XOR stays inside a 256-B half)
   else return (row >> 2) & 3;                           // 64-B rows
 }
 template <int CPR> __device__ __forceinline__ int tile_off(int row, int chunk) {

@@ -18,7 +18,7 @@ __global__ __launch_bounds__(256) void small_linear_kernel(const float* x, long 
     for (int r = 0; r < RT; ++r) acc[r] = 0.f;
     for (int v = lane; v < kv; v += 64) {
       float wf[8];
-      unpack8<Tag>(*(const uint4*)(w + ((long)col * ldw + v * 8) * 2), wf);
+      load8<Tag>(w + ((long)col * ldw + v * 8) * Elem<Tag>::ES, wf);
 #pragma unroll
       for (int r = 0; r < RT; ++r) {
         if (r0 + r < rows) {
@@ -71,19 +71,20 @@ __global__ void prep_input_kernel(const float* lat, const float* img, const floa
     const long bf = i / hw;
     const int f = (int)(bf % frames);
     const int b = (int)(bf / frames);
-    unsigned short* o = (unsigned short*)(x + i * cpad * 2);
+    constexpr int ES = Elem<Tag>::ES;
+    char* o = x + i * cpad * ES;
 #pragma unroll
     for (int c = 0; c < 4; ++c) {
-      o[c] = Cvt<Tag>::from_f32(lat[((long)f * 4 + c) * hw + p] * c_in);
-      o[4 + c] = Cvt<Tag>::from_f32(img[(((long)b * frames + f) * 4 + c) * hw + p]);
+      store1<Tag>(o + c * ES, lat[((long)f * 4 + c) * hw + p] * c_in);
+      store1<Tag>(o + (4 + c) * ES, img[(((long)b * frames + f) * 4 + c) * hw + p]);
     }
     int c0 = 8;
     if (cond) {
 #pragma unroll
-      for (int c = 0; c < 4; ++c) o[8 + c] = Cvt<Tag>::from_f32(cond[((long)f * 4 + c) * hw + p]);
+      for (int c = 0; c < 4; ++c) store1<Tag>(o + (8 + c) * ES, cond[((long)f * 4 + c) * hw + p]);
       c0 = 12;
     }
-    for (int c = c0; c < cpad; ++c) o[c] = 0;
+    for (int c = c0; c < cpad; ++c) store1<Tag>(o + c * ES, 0.f);
   }
 }
 
@@ -130,14 +131,14 @@ __global__ void nchw_to_tokens_kernel(const char* src, int c, int hw, char* dst,
     float v = 0.f;
     if (cc < c && pp < hw) {
       const long idx = ((long)img * c + cc) * hw + pp;
-      v = SRC_F32 ? ((const float*)src)[idx] : Cvt<Tag>::to_f32(((const unsigned short*)src)[idx]);
+      v = SRC_F32 ? ((const float*)src)[idx] : load1<Tag>(src + idx * Elem<Tag>::ES);
     }
     tile[i][tx] = v;
   }
   __syncthreads();
   for (int i = ty; i < 32; i += 8) {
     const int pp = p0 + i, cc = c0 + tx;
-    if (cc < c && pp < hw) ((unsigned short*)dst)[((long)img * hw + pp) * ld_dst + cc] = Cvt<Tag>::from_f32(tile[tx][i]);
+    if (cc < c && pp < hw) store1<Tag>(dst + (((long)img * hw + pp) * ld_dst + cc) * Elem<Tag>::ES, tile[tx][i]);
   }
 }
 
@@ -151,7 +152,7 @@ __global__ void tokens_to_nchw_kernel(const char* src, long ld_src, int c, int h
     float v = 0.f;
     if (cc < c && pp < hw) {
       const long idx = ((long)img * hw + pp) * ld_src + cc;
-      v = SRC_F32 ? ((const float*)src)[idx] : Cvt<Tag>::to_f32(((const unsigned short*)src)[idx]);
+      v = SRC_F32 ? ((const float*)src)[idx] : load1<Tag>(src + idx * Elem<Tag>::ES);
     }
     tile[i][tx] = v;
   }
@@ -161,7 +162,7 @@ __global__ void tokens_to_nchw_kernel(const char* src, long ld_src, int c, int h
     if (cc < c && pp < hw) {
       const long idx = ((long)img * c + cc) * hw + pp;
       if (DST_F32) ((float*)dst)[idx] = tile[tx][i];
-      else ((unsigned short*)dst)[idx] = Cvt<Tag>::from_f32(tile[tx][i]);
+      else store1<Tag>(dst + idx * Elem<Tag>::ES, tile[tx][i]);
     }
   }
 }
@@ -170,11 +171,11 @@ template <typename Tag>
 __global__ void add_scaled_kernel(const char* a, const char* b, float scale, char* y, long nvec) {
   for (long v = (long)blockIdx.x * blockDim.x + threadIdx.x; v < nvec; v += (long)gridDim.x * blockDim.x) {
     float fa[8], fb[8];
-    unpack8<Tag>(*(const uint4*)(a + v * 16), fa);
-    unpack8<Tag>(*(const uint4*)(b + v * 16), fb);
+    load8<Tag>(a + v * 8 * Elem<Tag>::ES, fa);
+    load8<Tag>(b + v * 8 * Elem<Tag>::ES, fb);
 #pragma unroll
     for (int e = 0; e < 8; ++e) fa[e] = fmaf(fb[e], scale, fa[e]);
-    *(uint4*)(y + v * 16) = pack8<Tag>(fa);
+    store8<Tag>(y + v * 8 * Elem<Tag>::ES, fa);
   }
 }
 
@@ -185,13 +186,15 @@ extern "C" int tt_small_linear(const float* x, int64_t ldx, int32_t rows, int32_
                                int32_t dtype, tt_stream_t stream) {
   if (!x || !w || !y) TT_FAIL(TT_EINVAL, "tt_small_linear: null operand");
   if (rows <= 0 || rows > 32 || n <= 0 || k <= 0 || (k & 7) || (ldx & 3) || (ldw & 7)) TT_FAIL(TT_EINVAL, "tt_small_linear: rows 1..32, k %% 8 == 0, ldx %% 4 == 0");
-  if (dtype != TT_BF16 && dtype != TT_F16) TT_FAIL(TT_EINVAL, "tt_small_linear: bad dtype");
+  if (dtype != TT_BF16 && dtype != TT_F16 && dtype != TT_F32) TT_FAIL(TT_EINVAL, "tt_small_linear: bad dtype");
   hipStream_t st = (hipStream_t)stream;
   const dim3 grid((n + 3) / 4), block(256);
   if (dtype == TT_BF16)
     hipLaunchKernelGGL((small_linear_kernel<bf16_tag, 4>), grid, block, 0, st, x, (long)ldx, rows, k, (const char*)w, (long)ldw, n, bias, act_in, act_out, accumulate, y, (long)ldy);
-  else
+  else if (dtype == TT_F16)
     hipLaunchKernelGGL((small_linear_kernel<f16_tag, 4>), grid, block, 0, st, x, (long)ldx, rows, k, (const char*)w, (long)ldw, n, bias, act_in, act_out, accumulate, y, (long)ldy);
+  else
+    hipLaunchKernelGGL((small_linear_kernel<f32_tag, 4>), grid, block, 0, st, x, (long)ldx, rows, k, (const char*)w, (long)ldw, n, bias, act_in, act_out, accumulate, y, (long)ldy);
   TT_CHECK_LAUNCH("tt_small_linear");
   return TT_OK;
 }
@@ -209,12 +212,13 @@ extern "C" int tt_prep_model_input(const float* latents, const float* image_late
                                    int32_t dtype, tt_stream_t stream) {
   if (!latents || !image_latents || !sigmas || !x) TT_FAIL(TT_EINVAL, "tt_prep_model_input: null operand");
   if (cpad < (cond ? 12 : 8) || (cpad & 7) || batch <= 0 || frames <= 0 || step < 0) TT_FAIL(TT_EINVAL, "tt_prep_model_input: cpad/batch/frames");
-  if (dtype != TT_BF16 && dtype != TT_F16) TT_FAIL(TT_EINVAL, "tt_prep_model_input: bad dtype");
+  if (dtype != TT_BF16 && dtype != TT_F16 && dtype != TT_F32) TT_FAIL(TT_EINVAL, "tt_prep_model_input: bad dtype");
   const long total = (long)batch * frames * h * w;
   long blocks = (total + 255) / 256; if (blocks > 2048) blocks = 2048;
   hipStream_t st = (hipStream_t)stream;
   if (dtype == TT_BF16) hipLaunchKernelGGL(prep_input_kernel<bf16_tag>, dim3((unsigned)blocks), dim3(256), 0, st, latents, image_latents, cond, sigmas, step, batch, frames, h * w, cpad, (char*)x);
-  else hipLaunchKernelGGL(prep_input_kernel<f16_tag>, dim3((unsigned)blocks), dim3(256), 0, st, latents, image_latents, cond, sigmas, step, batch, frames, h * w, cpad, (char*)x);
+  else if (dtype == TT_F16) hipLaunchKernelGGL(prep_input_kernel<f16_tag>, dim3((unsigned)blocks), dim3(256), 0, st, latents, image_latents, cond, sigmas, step, batch, frames, h * w, cpad, (char*)x);
+  else hipLaunchKernelGGL(prep_input_kernel<f32_tag>, dim3((unsigned)blocks), dim3(256), 0, st, latents, image_latents, cond, sigmas, step, batch, frames, h * w, cpad, (char*)x);
   TT_CHECK_LAUNCH("tt_prep_model_input");
   return TT_OK;
 }
@@ -244,12 +248,13 @@ extern "C" int tt_cfg3_euler_step(const float* eps, int32_t ld_eps, float* laten
 extern "C" int tt_nchw_to_tokens(const void* src, int32_t src_f32, int32_t nimg, int32_t c, int32_t hw, void* dst, int64_t ld_dst,
                                  int32_t dtype, tt_stream_t stream) {
   if (!src || !dst || nimg <= 0 || c <= 0 || hw <= 0 || ld_dst < c) TT_FAIL(TT_EINVAL, "tt_nchw_to_tokens: bad arguments");
-  if (dtype != TT_BF16 && dtype != TT_F16) TT_FAIL(TT_EINVAL, "tt_nchw_to_tokens: bad dtype");
+  if (dtype != TT_BF16 && dtype != TT_F16 && dtype != TT_F32) TT_FAIL(TT_EINVAL, "tt_nchw_to_tokens: bad dtype");
   const dim3 grid((hw + 31) / 32, (c + 31) / 32, nimg), block(256);
   hipStream_t st = (hipStream_t)stream;
 #define TT_N2T(TAG, F) hipLaunchKernelGGL((nchw_to_tokens_kernel<TAG, F>), grid, block, 0, st, (const char*)src, c, hw, (char*)dst, (long)ld_dst)
   if (dtype == TT_BF16) { if (src_f32) TT_N2T(bf16_tag, true); else TT_N2T(bf16_tag, false); }
-  else { if (src_f32) TT_N2T(f16_tag, true); else TT_N2T(f16_tag, false); }
+  else if (dtype == TT_F16) { if (src_f32) TT_N2T(f16_tag, true); else TT_N2T(f16_tag, false); }
+  else TT_N2T(f32_tag, true);
 #undef TT_N2T
   TT_CHECK_LAUNCH("tt_nchw_to_tokens");
   return TT_OK;
@@ -258,16 +263,18 @@ extern "C" int tt_nchw_to_tokens(const void* src, int32_t src_f32, int32_t nimg,
 extern "C" int tt_tokens_to_nchw(const void* src, int32_t src_f32, int64_t ld_src, int32_t nimg, int32_t c, int32_t hw, void* dst,
                                  int32_t dst_f32, int32_t dtype, tt_stream_t stream) {
   if (!src || !dst || nimg <= 0 || c <= 0 || hw <= 0 || ld_src < c) TT_FAIL(TT_EINVAL, "tt_tokens_to_nchw: bad arguments");
-  if (dtype != TT_BF16 && dtype != TT_F16) TT_FAIL(TT_EINVAL, "tt_tokens_to_nchw: bad dtype");
+  if (dtype != TT_BF16 && dtype != TT_F16 && dtype != TT_F32) TT_FAIL(TT_EINVAL, "tt_tokens_to_nchw: bad dtype");
   const dim3 grid((hw + 31) / 32, (c + 31) / 32, nimg), block(256);
   hipStream_t st = (hipStream_t)stream;
 #define TT_T2N(TAG, S, D) hipLaunchKernelGGL((tokens_to_nchw_kernel<TAG, S, D>), grid, block, 0, st, (const char*)src, (long)ld_src, c, hw, (char*)dst)
   if (dtype == TT_BF16) {
     if (src_f32) { if (dst_f32) TT_T2N(bf16_tag, true, true); else TT_T2N(bf16_tag, true, false); }
     else { if (dst_f32) TT_T2N(bf16_tag, false, true); else TT_T2N(bf16_tag, false, false); }
-  } else {
+  } else if (dtype == TT_F16) {
     if (src_f32) { if (dst_f32) TT_T2N(f16_tag, true, true); else TT_T2N(f16_tag, true, false); }
     else { if (dst_f32) TT_T2N(f16_tag, false, true); else TT_T2N(f16_tag, false, false); }
+  } else {
+    TT_T2N(f32_tag, true, true);
   }
 #undef TT_T2N
   TT_CHECK_LAUNCH("tt_tokens_to_nchw");
@@ -276,12 +283,13 @@ extern "C" int tt_tokens_to_nchw(const void* src, int32_t src_f32, int64_t ld_sr
 
 extern "C" int tt_add_scaled(const void* a, const void* b, float scale, void* y, int64_t n, int32_t dtype, tt_stream_t stream) {
   if (!a || !b || !y || n <= 0 || (n & 7)) TT_FAIL(TT_EINVAL, "tt_add_scaled: n must be a positive multiple of 8");
-  if (dtype != TT_BF16 && dtype != TT_F16) TT_FAIL(TT_EINVAL, "tt_add_scaled: bad dtype");
+  if (dtype != TT_BF16 && dtype != TT_F16 && dtype != TT_F32) TT_FAIL(TT_EINVAL, "tt_add_scaled: bad dtype");
   const long nvec = n >> 3;
   long blocks = (nvec + 255) / 256; if (blocks > 4096) blocks = 4096;
   hipStream_t st = (hipStream_t)stream;
   if (dtype == TT_BF16) hipLaunchKernelGGL(add_scaled_kernel<bf16_tag>, dim3((unsigned)blocks), dim3(256), 0, st, (const char*)a, (const char*)b, scale, (char*)y, nvec);
-  else hipLaunchKernelGGL(add_scaled_kernel<f16_tag>, dim3((unsigned)blocks), dim3(256), 0, st, (const char*)a, (const char*)b, scale, (char*)y, nvec);
+  else if (dtype == TT_F16) hipLaunchKernelGGL(add_scaled_kernel<f16_tag>, dim3((unsigned)blocks), dim3(256), 0, st, (const char*)a, (const char*)b, scale, (char*)y, nvec);
+  else hipLaunchKernelGGL(add_scaled_kernel<f32_tag>, dim3((unsigned)blocks), dim3(256), 0, st, (const char*)a, (const char*)b, scale, (char*)y, nvec);
   TT_CHECK_LAUNCH("tt_add_scaled");
   return TT_OK;
 }

@@ -15,869 +15,38 @@
 //   * MFMA operands are swapped (W fragment as the MFMA "A" operand) so each lane ends up with 4
 //     consecutive output columns of one row: 8-byte epilogue loads/stores.
 #include <stdlib.h>
-#include <type_traits>
-#include "common.h"
+#include "gemm_kernel.h"
+
+namespace ttg {
+// per-dtype instantiation units (gemm_inst_*.hip)
+void launch_bf16(GemmP& p, int cfg, hipStream_t st);
+void launch_f16(GemmP& p, int cfg, hipStream_t st);
+void launch_f32(GemmP& p, int cfg, hipStream_t st);
+void launch_sq320_bf16(const GemmP& p, hipStream_t st);
+void launch_sq320_f16(const GemmP& p, hipStream_t st);
+}
+using namespace ttg;
 
 namespace {
-
-struct GemmP {
-  const char* a0; const char* a1;
-  int k0, k1; long lda0, lda1;
-  const char* w; long ldw;
-  int m, n, mode;
-  int nimg, hin, win, hout, wout, stride, upsample;
-  int frames, hw;
-  const float* bias; float acc_scale;
-  const float* rowvec; int rowvec_rows; long ld_rowvec;
-  int geglu;
-  const char* residual; long ld_res;
-  const char* blend; long ld_blend; float alpha;
-  char* out; long ldo; int out_f32;
-  int out_col_hw, out_col_hwp;
-  int nk0, nk1, taps, kt_total;     // derived: K steps per source, taps, total K steps
-  int tiles_m, tiles_n;
-  unsigned a0_bytes, a1_bytes, w_bytes;   // extents for the buffer descriptors (< 2 GiB each)
-  unsigned out_bytes, res_bytes, blend_bytes, bias_bytes, rowvec_bytes, ws_bytes;   // epilogue descriptors (0 = absent)
-  int splitk;                       // > 1: block (tile, s) reduces K slice s and writes an fp32 slab to ws
-  float* ws;                        // [splitk][m][n] fp32 partial sums
-};
-
-
-// ---- optional per-block timeline (make timeline): thread 0 of every block stamps the 100 MHz wall clock
-#ifdef TT_GEMM_TIMELINE
-__device__ long long g_tl[8 * 8192];
-#define TL(i) do { if (threadIdx.x == 0 && blockIdx.x < 8192) g_tl[blockIdx.x * 8 + (i)] = wall_clock64(); } while (0)
-#else
-#define TL(i) do { } while (0)
-#endif
-
-// ---- branch-free global access for the epilogue: 128-bit buffer descriptors with hardware bounds checking.  An
-// offset of kInv (>= num_records) makes a load return 0 and drops a store, so ragged rows/columns and absent operands
-// (null base, 0 records) need no exec-masked branch -- with branches hipcc serialises every pass behind
-// `s_waitcnt vmcnt(0)` and the epilogue of one tile costs 4-8 us; straight-line it is ~1 us.
-constexpr int kInv = (int)0x80000000;
-typedef unsigned u32x2_t __attribute__((ext_vector_type(2)));
-typedef unsigned u32x4_t __attribute__((ext_vector_type(4)));
-__device__ __forceinline__ __amdgpu_buffer_rsrc_t make_rsrc(const void* ptr, unsigned bytes) {
-  return __builtin_amdgcn_make_buffer_rsrc((void*)ptr, 0, (int)bytes, 0x00020000);
-}
-__device__ __forceinline__ uint2 ld64(__amdgpu_buffer_rsrc_t r, int off) {
-  const u32x2_t v = __builtin_amdgcn_raw_buffer_load_b64(r, off, 0, 0);
-  return make_uint2(v.x, v.y);
-}
-__device__ __forceinline__ float4 ld128f(__amdgpu_buffer_rsrc_t r, int off) {
-  const u32x4_t v = __builtin_amdgcn_raw_buffer_load_b128(r, off, 0, 0);
-  return make_float4(__uint_as_float(v.x), __uint_as_float(v.y), __uint_as_float(v.z), __uint_as_float(v.w));
-}
-__device__ __forceinline__ void st64(__amdgpu_buffer_rsrc_t r, int off, unsigned a, unsigned b) {
-  __builtin_amdgcn_raw_buffer_store_b64((u32x2_t){a, b}, r, off, 0, 0);
-}
-__device__ __forceinline__ void st128f(__amdgpu_buffer_rsrc_t r, int off, float4 v) {
-  __builtin_amdgcn_raw_buffer_store_b128((u32x4_t){__float_as_uint(v.x), __float_as_uint(v.y), __float_as_uint(v.z), __float_as_uint(v.w)}, r, off, 0, 0);
-}
-
-// ---- epilogue on 4 consecutive output columns (gn .. gn+3) of row gm
-template <typename Tag, bool PRELOADED = false>
-__device__ __forceinline__ void epilogue_quad(const GemmP& p, int gm, int gn, float (&v)[4], uint2 res_pre = make_uint2(0, 0),
-                                              uint2 blend_pre = make_uint2(0, 0)) {
-  if (p.bias) {
-    const float4 b = *(const float4*)(p.bias + gn);
-    v[0] += b.x; v[1] += b.y; v[2] += b.z; v[3] += b.w;
-  }
-#pragma unroll
-  for (int e = 0; e < 4; ++e) v[e] *= p.acc_scale;
-  if (p.rowvec) {
-    const float4 b = *(const float4*)(p.rowvec + (long)(gm / p.rowvec_rows) * p.ld_rowvec + gn);
-    v[0] += b.x; v[1] += b.y; v[2] += b.z; v[3] += b.w;
-  }
-  if (p.residual) {
-    float r4[4];
-    unpack4<Tag>(PRELOADED ? res_pre : *(const uint2*)(p.residual + ((long)gm * p.ld_res + gn) * 2), r4);
-#pragma unroll
-    for (int e = 0; e < 4; ++e) v[e] += r4[e];
-  }
-  if (p.blend) {
-    float r4[4];
-    unpack4<Tag>(PRELOADED ? blend_pre : *(const uint2*)(p.blend + ((long)gm * p.ld_blend + gn) * 2), r4);
-#pragma unroll
-    for (int e = 0; e < 4; ++e) v[e] = p.alpha * r4[e] + (1.0f - p.alpha) * v[e];
-  }
-  if (p.out_f32) {
-    *(float4*)(p.out + ((long)gm * p.ldo + gn) * 4) = make_float4(v[0], v[1], v[2], v[3]);
-  } else if (p.out_col_hw > 0) {
-#pragma unroll
-    for (int e = 0; e < 4; ++e) {
-      const int c = gn + e;
-      const long oc = (long)(c / p.out_col_hw) * p.out_col_hwp + (c % p.out_col_hw);
-      *(unsigned short*)(p.out + ((long)gm * p.ldo + oc) * 2) = Cvt<Tag>::from_f32(v[e]);
-    }
-  } else {
-    *(uint2*)(p.out + ((long)gm * p.ldo + gn) * 2) = make_uint2(pack2<Tag>(v[0], v[1]), pack2<Tag>(v[2], v[3]));
-  }
-}
-
-template <int N> __device__ __forceinline__ void wait_vmcnt() {
-  asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
-}
-// wait until at most `tiles` of the G-load groups issued last are still in flight (tiles <= 3)
-template <int G> __device__ __forceinline__ void wait_tiles(int tiles) {
-  static_assert(3 * G <= 63, "vmcnt field is 6 bits");
-  if (tiles <= 0) wait_vmcnt<0>();
-  else if (tiles == 1) wait_vmcnt<G>();
-  else if (tiles == 2) wait_vmcnt<2 * G>();
-  else wait_vmcnt<3 * G>();
-}
-
-// LDS bytes of one workgroup and the waves per SIMD the register allocator must leave room for: as many workgroups per
-// CU as the 160 KiB of LDS admit (at most 2 -- more did not pay), i.e. blocks * waves / 4 SIMDs.  Declaring it keeps e.g.
-// the 256x128 8-wave kernel at <= 128 VGPRs (130 would halve its occupancy).
-constexpr int gemm_lds_bytes(int BM, int BN, int BK, int NST, int NT) {
-  return NST * (((BM * (BK / 8) + NT - 1) / NT) + ((BN * (BK / 8) + NT - 1) / NT)) * NT * 16;
-}
-constexpr int gemm_min_waves(int BM, int BN, int BK, int NST, int NT) {
-  const int blocks = (160 * 1024) / gemm_lds_bytes(BM, BN, BK, NST, NT) >= 2 ? 2 : 1;
-  return blocks * (NT / 64) / 4;
-}
-
-template <typename Tag, int BM, int BN, int BK, int NST, int WGM, int WGN, int MODE>
-__global__ __launch_bounds__(64 * WGM * WGN, gemm_min_waves(BM, BN, BK, NST, 64 * WGM * WGN))
-void gemm_kernel(const GemmP p) {
-  extern __shared__ __attribute__((aligned(16))) char smem[];
-  TL(0);
-  constexpr int NT = 64 * WGM * WGN;                   // threads
-  constexpr int CPR = BK / 8;                          // 16-byte chunks per tile row
-  constexpr int ROWB = BK * 2;
-  constexpr int WTM = BM / WGM, WTN = BN / WGN, FM = WTM / 32, FN = WTN / 32;
-  // 16-byte chunks staged per thread per tile; when the tile does not divide evenly the last pass is padded
-  // (rows >= BM/BN of the LDS image are never read; their lanes load the zero page so every wave issues the
-  // same number of loads and the counted vmcnt stays valid)
-  constexpr int AR = (BM * CPR + NT - 1) / NT, BR = (BN * CPR + NT - 1) / NT;
-  constexpr int A_BYTES = AR * NT * 16, B_BYTES = BR * NT * 16, STAGE = A_BYTES + B_BYTES;
-  constexpr int G = AR + BR;
-  constexpr int RPI = NT / CPR;                        // tile rows covered per staging pass
-  static_assert(NT % CPR == 0 && NST >= 2 && NST <= 5 && WTM % 32 == 0 && WTN % 32 == 0, "tile/threads mismatch");
-
-  const int tid = threadIdx.x, lane = tid & 63;
-  const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
-
-  // XCD-aware tile order: the dispatcher places block b on XCD b%8; give each XCD a contiguous run of
-  // tiles (same A rows, neighbouring W columns) so its private L2 sees the reuse (guide T1, bijective form).
-  int bid = blockIdx.x;
-  {
-    const int nwg = gridDim.x, q = nwg >> 3, r = nwg & 7, xcd = bid & 7, idx = bid >> 3;
-    bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
-  }
-  const int split = p.splitk > 1 ? bid % p.splitk : 0;      // slices of one tile sit next to each other
-  if (p.splitk > 1) bid /= p.splitk;
-  const int tile_m = bid / p.tiles_n, tile_n = bid - tile_m * p.tiles_n;
-  const int m0 = tile_m * BM, n0 = tile_n * BN;
-  // K-tile range of this block
-  const int kt_lo = (int)((long)p.kt_total * split / p.splitk);
-  const int KT = (int)((long)p.kt_total * (split + 1) / p.splitk) - kt_lo;
-
-  // ---- staging: buffer_load ... lds through 128-bit resource descriptors.  Every lane owns a 32-bit byte offset per
-  // staged 16-byte chunk (computed once per tile, or once per conv tap); the K position is a SCALAR offset.  Lanes that
-  // must read zeros (ragged M/N, conv halo, K tail) use an offset beyond num_records: the hardware bounds check returns 0.
-  // This keeps the per-K-step instruction count at ~1 per load (the loop is otherwise instruction-issue bound).
-  constexpr int INV = (int)0x80000000;
-  const __amdgpu_buffer_rsrc_t ra0 = __builtin_amdgcn_make_buffer_rsrc((void*)p.a0, 0, p.a0_bytes, 0x00020000);
-  const __amdgpu_buffer_rsrc_t ra1 = __builtin_amdgcn_make_buffer_rsrc((void*)(p.a1 ? p.a1 : p.a0), 0, p.a1_bytes, 0x00020000);
-  const __amdgpu_buffer_rsrc_t rw = __builtin_amdgcn_make_buffer_rsrc((void*)p.w, 0, p.w_bytes, 0x00020000);
-  const int crow = tid / CPR, cchunk = tid % CPR;
-  int a_chunk[AR];              // source chunk (swizzled) per staged row
-  int va0[AR], va1[AR];         // byte offsets into a0 / a1 for the current tap
-  int a_img[AR], a_y[AR], a_x[AR];
-  bool a_valid[AR];
-#pragma unroll
-  for (int i = 0; i < AR; ++i) {
-    const int r = i * RPI + crow;
-    a_chunk[i] = cchunk ^ tile_swz<CPR>(r);
-    const int gm = m0 + r;
-    a_valid[i] = gm < p.m && r < BM;
-    const int g = a_valid[i] ? gm : 0;
-    va0[i] = va1[i] = INV;
-    a_img[i] = a_y[i] = a_x[i] = 0;
-    if constexpr (MODE == 0) {
-      if (a_valid[i]) {
-        va0[i] = (int)(((long)g * p.lda0 + a_chunk[i] * 8) * 2);
-        va1[i] = (int)(((long)g * p.lda1 + a_chunk[i] * 8) * 2);
-      }
-    } else if constexpr (MODE == 1) {
-      const int hwo = p.hout * p.wout;
-      a_img[i] = g / hwo;
-      const int rem = g - a_img[i] * hwo;
-      a_y[i] = rem / p.wout;
-      a_x[i] = rem - a_y[i] * p.wout;
-    } else {
-      a_img[i] = (g / p.hw) % p.frames;   // frame index
-      a_y[i] = g;                         // row
-    }
-  }
-  int b_chunk[BR], vb[BR];
-#pragma unroll
-  for (int i = 0; i < BR; ++i) {
-    const int r = i * RPI + crow;
-    b_chunk[i] = cchunk ^ tile_swz<CPR>(r);
-    const int gn = n0 + r;
-    vb[i] = (gn < p.n && r < BN) ? (int)(((long)gn * p.ldw + b_chunk[i] * 8) * 2) : INV;
-  }
-
-  // K-step iterator state for the NEXT tile to stage (uniform)
-  int s_tap, s_src, s_kc;
-  {
-    const int per_tap = p.nk0 + p.nk1;
-    s_tap = kt_lo / per_tap;
-    const int rem = kt_lo - s_tap * per_tap;
-    s_src = rem >= p.nk0 ? 1 : 0;
-    s_kc = rem - (s_src ? p.nk0 : 0);
-  }
-  bool tap_dirty = true;
-  auto stage = [&](int slot) {
-    if constexpr (MODE != 0) {
-      if (tap_dirty) {                       // new tap: refresh the per-lane row offsets (uniform branch)
-        tap_dirty = false;
-#pragma unroll
-        for (int i = 0; i < AR; ++i) {
-          bool ok = a_valid[i];
-          long row;
-          if constexpr (MODE == 1) {
-            const int dy = s_tap / 3 - 1, dx = s_tap - (dy + 1) * 3 - 1;
-            int iy = a_y[i] * p.stride + dy, ix = a_x[i] * p.stride + dx;
-            const int hv = p.upsample ? p.hin * 2 : p.hin, wv = p.upsample ? p.win * 2 : p.win;
-            ok = ok && iy >= 0 && iy < hv && ix >= 0 && ix < wv;
-            if (p.upsample) { iy >>= 1; ix >>= 1; }
-            row = ((long)a_img[i] * p.hin + iy) * p.win + ix;
-          } else {
-            const int f = a_img[i] + s_tap - 1;
-            ok = ok && f >= 0 && f < p.frames;
-            row = (long)a_y[i] + (long)(s_tap - 1) * p.hw;
-          }
-          va0[i] = ok ? (int)((row * p.lda0 + a_chunk[i] * 8) * 2) : INV;
-          va1[i] = ok ? (int)((row * p.lda1 + a_chunk[i] * 8) * 2) : INV;
-        }
-      }
-    }
-    // everything below is wave-uniform except the per-lane offsets; force the scalars into SGPRs so the buffer
-    // instructions get their soffset / descriptor without waterfall loops (cdna guide T20)
-    const int src = __builtin_amdgcn_readfirstlane(s_src);
-    const int ksrc = src ? p.k1 : p.k0;
-    const int kbase = __builtin_amdgcn_readfirstlane(s_kc) * BK;
-    const bool tail = kbase + BK > ksrc;     // only the last K step of a source can have dead chunks
-    char* lds_a = smem + slot * STAGE + wid * 1024;
-    char* lds_b = smem + slot * STAGE + A_BYTES + wid * 1024;
-    const int soff_a = kbase * 2;
-    const int soff_w = __builtin_amdgcn_readfirstlane(
-        (int)(((long)s_tap * (p.k0 + p.k1) + (src ? p.k0 : 0) + kbase) * 2));
-    auto issue = [&](const __amdgpu_buffer_rsrc_t& ra, const int (&va)[AR], auto has_tail) {
-#pragma unroll
-      for (int i = 0; i < AR; ++i) {
-        int v = va[i];
-        if constexpr (decltype(has_tail)::value) { if (kbase + a_chunk[i] * 8 >= ksrc) v = INV; }
-        __builtin_amdgcn_raw_ptr_buffer_load_lds(ra, (__attribute__((address_space(3))) void*)(lds_a + i * (NT * 16)), 16, v, soff_a, 0, 0);
-      }
-#pragma unroll
-      for (int i = 0; i < BR; ++i) {
-        int v = vb[i];
-        if constexpr (decltype(has_tail)::value) { if (kbase + b_chunk[i] * 8 >= ksrc) v = INV; }
-        __builtin_amdgcn_raw_ptr_buffer_load_lds(rw, (__attribute__((address_space(3))) void*)(lds_b + i * (NT * 16)), 16, v, soff_w, 0, 0);
-      }
-    };
-    if (!tail) {
-      if (!src) issue(ra0, va0, std::false_type{}); else issue(ra1, va1, std::false_type{});
-    } else {
-      if (!src) issue(ra0, va0, std::true_type{}); else issue(ra1, va1, std::true_type{});
-    }
-    if (++s_kc == (s_src ? p.nk1 : p.nk0)) {
-      s_kc = 0;
-      if (s_src == 0 && p.nk1 > 0) s_src = 1;
-      else { s_src = 0; ++s_tap; tap_dirty = true; }
-    }
-  };
-
-  const int wr = wid / WGN, wc = wid - wr * WGN;
-  f32x16_t acc[FM][FN];
-#pragma unroll
-  for (int i = 0; i < FM; ++i)
-#pragma unroll
-    for (int j = 0; j < FN; ++j)
-#pragma unroll
-      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
-
-  const int l31 = lane & 31, hi = lane >> 5;
-  int a_lds_row[FM], b_lds_row[FN];
-#pragma unroll
-  for (int i = 0; i < FM; ++i) a_lds_row[i] = wr * WTM + i * 32 + l31;
-#pragma unroll
-  for (int j = 0; j < FN; ++j) b_lds_row[j] = wc * WTN + j * 32 + l31;
-
-  constexpr int KS = BK / 16;                 // MFMA k sub-steps per tile (even)
-  // Fragment reads are raw ds_read_b128 (common.h): with compiler-visible LDS loads hipcc puts `s_waitcnt vmcnt(0)` in
-  // front of the first read of every K step -- AFTER the next tile's DMA has been issued -- so load latency and MFMA time
-  // add up instead of overlapping (1.1-1.5 us per 64-deep step, measured).  The reads of one fragment set are retired
-  // by lds_wait<reads issued after them>() before the MFMAs that consume them.
-  constexpr int NF = FM + FN;                 // ds_read_b128 per fragment set
-  const unsigned lds_base = lds_addr(smem);
-  auto read_frags = [&](unsigned sa, int ks, raw_u32x4_t (&af)[FM], raw_u32x4_t (&bf)[FN]) {
-    const unsigned sb = sa + A_BYTES;
-    const int chunk = ks * 2 + hi;
-#pragma unroll
-    for (int i = 0; i < FM; ++i) af[i] = lds_read16_raw(sa + tile_off<CPR>(a_lds_row[i], chunk));
-#pragma unroll
-    for (int j = 0; j < FN; ++j) bf[j] = lds_read16_raw(sb + tile_off<CPR>(b_lds_row[j], chunk));
-  };
-  auto mma = [&](const raw_u32x4_t (&af)[FM], const raw_u32x4_t (&bf)[FN]) {
-#pragma unroll
-    for (int i = 0; i < FM; ++i)
-#pragma unroll
-      for (int j = 0; j < FN; ++j)
-        acc[i][j] = Cvt<Tag>::mfma32(make_uint4(bf[j].x, bf[j].y, bf[j].z, bf[j].w), make_uint4(af[i].x, af[i].y, af[i].z, af[i].w), acc[i][j]);
-  };
-
-  // residual operands of every (row, quad) this lane will finish (epilogue layout, see below): ONE batch of loads.
-  // Tiles with register headroom issue it BEFORE the main loop so the whole K loop hides the latency; the 256-row
-  // tiles (128-VGPR budget) issue it at the top of the epilogue, where it overlaps the barrier and the LDS transposition.
-  // (The AlphaBlender source is usually the residual tensor itself -- temporal ResBlock -- and then shares the
-  // preloaded value; a distinct blend tensor is read in-pass.)
-  constexpr int NCH = (FN + 1) / 2;                    // 64-column chunks per fragment row
-  constexpr bool EARLY_RES = BM <= 128;
-  uint2 resv[EARLY_RES ? FM : 1][EARLY_RES ? NCH : 1][8];   // 256-row tiles read the residual inside the passes
-  const bool direct = (p.out_col_hw > 0 || p.out_f32) && p.splitk == 1;   // rare layouts keep the simple per-fragment path
-  const bool blend_is_res = p.blend && p.blend == p.residual && p.ld_blend == p.ld_res;
-  auto preload_residual = [&]() {
-    if constexpr (EARLY_RES) if (!direct && !p.geglu && p.splitk == 1) {
-      const __amdgpu_buffer_rsrc_t r_res = make_rsrc(p.residual, p.res_bytes);
-#pragma unroll
-      for (int i = 0; i < FM; ++i)
-#pragma unroll
-        for (int c = 0; c < NCH; ++c) {
-          const int nfr = (2 * c + 1 < FN) ? 2 : 1;
-          const int q_per_row = nfr * 8, rows_per_pass = 64 / q_per_row;
-          const int gn = n0 + wc * WTN + c * 64 + (lane % q_per_row) * 4;
-#pragma unroll
-          for (int pass = 0; pass < 8; ++pass) {
-            resv[i][c][pass] = make_uint2(0, 0);
-            if (pass * rows_per_pass < 32) {
-              const int gm = m0 + wr * WTM + i * 32 + pass * rows_per_pass + lane / q_per_row;
-              resv[i][c][pass] = ld64(r_res, (gm < p.m && gn < p.n) ? (int)(((long)gm * p.ld_res + gn) * 2) : kInv);
-            }
-          }
-        }
-    }
-  };
-  if constexpr (NST == 2) {
-    // plain double buffer: wait tile kt, barrier, issue tile kt+1, compute tile kt.  The first tile is requested before
-    // the residual batch (whose address arithmetic costs ~2 us); the first wait covers both.
-    stage(0);
-    preload_residual();
-    TL(1);
-    for (int kt = 0; kt < KT; ++kt) {
-      wait_vmcnt<0>();
-      __builtin_amdgcn_s_barrier();
-      asm volatile("" ::: "memory");
-#ifdef TT_GEMM_TIMELINE
-      if (kt == 0) TL(2);
-#endif
-      if (kt + 1 < KT) stage((kt + 1) & 1);
-      const unsigned sa = lds_base + (kt & 1) * STAGE;
-      raw_u32x4_t af[2][FM], bf[2][FN];         // fragment sets double-buffered: set ks+1 is read under the MFMAs of ks
-      read_frags(sa, 0, af[0], bf[0]);
-#pragma unroll
-      for (int ks = 0; ks < KS; ++ks) {
-        if (ks + 1 < KS) {
-          read_frags(sa, ks + 1, af[(ks + 1) & 1], bf[(ks + 1) & 1]);
-          lds_wait<NF>();
-        } else {
-          lds_wait<0>();
-        }
-        mma(af[ks & 1], bf[ks & 1]);
-      }
-    }
-  } else {
-    preload_residual();                       // before the ring fill: the counted waits below assume the DMAs come last
-    TL(1);
-    // software pipeline: fragments double-buffered in registers; the wait+barrier for tile kt+1 sits BEFORE the last
-    // MFMA group of tile kt, so the first fragments of tile kt+1 are read (and tile kt+NST-1 is issued) under MFMAs.
-#pragma unroll
-    for (int s = 0; s < NST - 1; ++s)
-      if (s < KT) stage(s);
-    wait_tiles<G>(min(KT - 1, NST - 2));      // tile 0 landed
-    __builtin_amdgcn_s_barrier();
-    asm volatile("" ::: "memory");
-    raw_u32x4_t afA[FM], bfA[FN], afB[FM], bfB[FN];
-    read_frags(lds_base, 0, afA, bfA);
-    int slot = 0, fill = NST - 1;             // slot of tile kt ; slot the next staged tile goes to
-    for (int kt = 0; kt < KT; ++kt) {
-      const unsigned sa = lds_base + slot * STAGE;
-      const int nslot = slot + 1 == NST ? 0 : slot + 1;
-#pragma unroll
-      for (int ks = 0; ks < KS; ks += 2) {
-        read_frags(sa, ks + 1, afB, bfB);
-        lds_wait<NF>();                       // set A (issued before set B) has landed
-        mma(afA, bfA);
-        if (ks + 2 < KS) {
-          read_frags(sa, ks + 2, afA, bfA);
-          lds_wait<NF>();                     // set B has landed
-        } else if (kt + 1 < KT) {
-          // tile kt+1 must have landed; tiles kt+2 .. min(KT-1, kt+NST-2) may stay in flight
-          wait_tiles<G>(min(KT - 2 - kt, NST - 3));
-          __builtin_amdgcn_s_barrier();       // all waves: tile kt+1 visible, tile kt-1's slot free
-          asm volatile("" ::: "memory");
-          if (kt + NST - 1 < KT) stage(fill);
-          read_frags(lds_base + nslot * STAGE, 0, afA, bfA);
-          lds_wait<NF>();
-        } else {
-          lds_wait<0>();
-        }
-        mma(afB, bfB);
-      }
-      slot = nslot;
-      fill = fill + 1 == NST ? 0 : fill + 1;
-    }
-  }
-
-  // ---- epilogue.  The MFMA layout gives a lane row m = .. + l31 and columns n = .. + 8g + 4hi + {0..3}: stored
-  // directly, one instruction would touch 32 rows x 16 bytes.  Instead each wave transposes its accumulators through a
-  // private LDS strip (fp32, 32 rows x 64 columns at a time) and re-reads them so that 16 consecutive lanes cover 64
-  // consecutive columns of one row: every residual/blend load and every store instruction then covers 4 rows x 128
-  // contiguous bytes.  All global accesses go through bounds-checked descriptors (see make_rsrc) so the pass loops are
-  // straight-line code; the arithmetic (fp32, same order) is what epilogue_quad does.
-  TL(3);
-  if (!direct) {
-    const __amdgpu_buffer_rsrc_t r_bias = make_rsrc(p.bias, p.bias_bytes);
-    const __amdgpu_buffer_rsrc_t r_out = p.splitk > 1 ? make_rsrc(p.ws, p.ws_bytes) : make_rsrc(p.out, p.out_bytes);
-    // strip = 32 rows x 256 bytes per wave, 16-byte quads XOR-swizzled by the row (no padding: 8 KiB per wave)
-    auto strip_off = [](int row, int quad, int nq) { return row * 256 + ((quad ^ (row & (nq - 1))) << 4); };
-    char* ebuf = smem + wid * 8192;
-    static_assert(WGM * WGN * 8192 <= NST * STAGE, "epilogue strips do not fit the ring");
-    if (!p.geglu) {
-      // bias of the 4 columns this lane finishes in each 64-column chunk (row-independent: loaded once)
-      float4 bias4[NCH];
-#pragma unroll
-      for (int c = 0; c < NCH; ++c) {
-        const int q_per_row = ((2 * c + 1 < FN) ? 2 : 1) * 8;
-        const int gn = n0 + wc * WTN + c * 64 + (lane % q_per_row) * 4;
-        bias4[c] = ld128f(r_bias, gn < p.n ? gn * 4 : kInv);
-      }
-      const float alpha = p.blend ? p.alpha : 0.0f, one_m_alpha = 1.0f - alpha;
-      __syncthreads();                                 // all waves are done with the operand ring
-      TL(4);
-      // Operand variants (uniform dispatch, each straight-line):
-      //   FILM   the row vector (time-embedding FiLM term, one vector per rowvec_rows output rows) of the <= 2 row groups
-      //          a 32-row fragment spans is loaded up front and selected per row;
-      //   INPASS operands that cannot be held in registers are loaded inside the pass batches: a blend tensor distinct
-      //          from the residual, a row vector with groups shorter than 32 rows, and -- on the 256-row tiles, whose
-      //          128-VGPR budget has no room for the preload -- the residual.  A load issued after a store waits for
-      //          that store (in-order vmcnt), so each batch loads first and stores last; the planner keeps such
-      //          epilogues off the 256-row tiles.
-      auto run = [&](auto film_tag, auto inpass_tag) {
-        constexpr bool FILM = decltype(film_tag)::value, INPASS = decltype(inpass_tag)::value;
-        const __amdgpu_buffer_rsrc_t r_rv = make_rsrc(p.rowvec, (FILM || INPASS) ? p.rowvec_bytes : 0);
-        const __amdgpu_buffer_rsrc_t r_bl = make_rsrc(p.blend, INPASS ? p.blend_bytes : 0);
-        const __amdgpu_buffer_rsrc_t r_res = make_rsrc(p.residual, (INPASS && !EARLY_RES) ? p.res_bytes : 0);
-        const int rv_rows = p.rowvec ? p.rowvec_rows : 1;
-#pragma unroll
-        for (int i = 0; i < FM; ++i) {
-          const int mb = m0 + wr * WTM + i * 32;
-          const int grp0 = mb / rv_rows;                 // row group of the fragment's first row (uniform)
-          const int grp_split = (grp0 + 1) * rv_rows;    // first row of the next group
-#pragma unroll
-          for (int jc = 0; jc < FN; jc += 2) {
-            const int nfr = (jc + 1 < FN) ? 2 : 1;       // fragments in this chunk (compile-time after unrolling)
-            const int q_per_row = nfr * 8;               // 4-column quads per strip row
-            const int rows_per_pass = 64 / q_per_row;
-            const int qq = lane % q_per_row, rr = lane / q_per_row;
-            const int gn = n0 + wc * WTN + jc * 32 + qq * 4;
-            const float4 b4 = bias4[jc / 2];
-            float4 film_lo = make_float4(0.f, 0.f, 0.f, 0.f), film_hi = film_lo;
-            if constexpr (FILM) {
-              film_lo = ld128f(r_rv, (mb < p.m && gn < p.n) ? (int)(((long)grp0 * p.ld_rowvec + gn) * 4) : kInv);
-              film_hi = ld128f(r_rv, (grp_split < p.m && gn < p.n) ? (int)(((long)(grp0 + 1) * p.ld_rowvec + gn) * 4) : kInv);
-            }
-#pragma unroll
-            for (int jj = 0; jj < 2; ++jj) {
-              if (jc + jj < FN) {
-#pragma unroll
-                for (int g = 0; g < 4; ++g)
-                  *(float4*)(ebuf + strip_off(l31, jj * 8 + 2 * g + hi, nfr * 8)) =
-                      make_float4(acc[i][jc + jj][g * 4], acc[i][jc + jj][g * 4 + 1], acc[i][jc + jj][g * 4 + 2], acc[i][jc + jj][g * 4 + 3]);
-              }
-            }
-            constexpr int PB = INPASS ? (BM > 128 ? 2 : 4) : 8;   // passes per batch, sized to the register budget
-#pragma unroll
-            for (int pb = 0; pb < 8; pb += PB) {
-              uint2 rqv[PB], blv[PB];
-              float4 rvv[PB];
-#pragma unroll
-              for (int k = 0; k < PB; ++k) {
-                const int pass = pb + k;
-                rqv[k] = blv[k] = make_uint2(0, 0);
-                rvv[k] = make_float4(0.f, 0.f, 0.f, 0.f);
-                if (pass * rows_per_pass < 32) {
-                  const int gm = mb + pass * rows_per_pass + rr;
-                  const bool ok = gm < p.m && gn < p.n;
-                  if constexpr (EARLY_RES) rqv[k] = resv[i][jc / 2][pass];
-                  else if constexpr (INPASS) rqv[k] = ld64(r_res, ok ? (int)(((long)gm * p.ld_res + gn) * 2) : kInv);
-                  if constexpr (INPASS) {
-                    rvv[k] = ld128f(r_rv, ok ? (int)(((long)(gm / rv_rows) * p.ld_rowvec + gn) * 4) : kInv);
-                    blv[k] = ld64(r_bl, ok ? (int)(((long)gm * p.ld_blend + gn) * 2) : kInv);
-                  }
-                }
-              }
-#pragma unroll
-              for (int k = 0; k < PB; ++k) {
-                const int pass = pb + k;
-                if (pass * rows_per_pass < 32) {
-                  const int r = pass * rows_per_pass + rr;
-                  const float4 t = *(const float4*)(ebuf + strip_off(r, qq, q_per_row));
-                  const int gm = mb + r;
-                  const bool ok = gm < p.m && gn < p.n;
-                  if (p.splitk > 1) {                    // uniform: fp32 partial sums of K slice `split`
-                    st128f(r_out, ok ? (int)((((long)split * p.m + gm) * p.n + gn) * 4) : kInv, t);
-                  } else {
-                    float v[4] = {(t.x + b4.x) * p.acc_scale, (t.y + b4.y) * p.acc_scale, (t.z + b4.z) * p.acc_scale,
-                                  (t.w + b4.w) * p.acc_scale};
-                    const uint2 rq = rqv[k];
-                    uint2 bq = rq;
-                    if constexpr (FILM) {
-                      const float4 f = gm >= grp_split ? film_hi : film_lo;
-                      v[0] += f.x; v[1] += f.y; v[2] += f.z; v[3] += f.w;
-                    }
-                    if constexpr (INPASS) {
-                      v[0] += rvv[k].x; v[1] += rvv[k].y; v[2] += rvv[k].z; v[3] += rvv[k].w;
-                      bq = (p.blend && !blend_is_res) ? blv[k] : rq;
-                    }
-                    float r4[4], b4v[4];
-                    unpack4<Tag>(rq, r4);
-                    unpack4<Tag>(bq, b4v);
-#pragma unroll
-                    for (int e = 0; e < 4; ++e) v[e] = alpha * b4v[e] + one_m_alpha * (v[e] + r4[e]);
-                    st64(r_out, ok ? (int)(((long)gm * p.ldo + gn) * 2) : kInv, pack2<Tag>(v[0], v[1]), pack2<Tag>(v[2], v[3]));
-                  }
-                }
-              }
-            }
-          }
-        }
-      };
-      const bool inpass = (p.blend && !blend_is_res) || (p.rowvec && p.rowvec_rows < 32) || (!EARLY_RES && p.residual);
-      if (inpass) run(std::false_type{}, std::true_type{});
-      else if (p.rowvec) run(std::true_type{}, std::false_type{});
-      else run(std::false_type{}, std::false_type{});
-    } else {
-      // GEGLU: value/gate pairs are lane-local (regs g=0/2 value, g=1/3 gate); gelu in registers, then the 16
-      // output columns of each fragment go through the strip: 2 fragments -> 32 output columns = 64 bytes per row.
-      float4 bval[FN][2], bgate[FN][2];                  // bias of this lane's value / gate quads (row-independent)
-#pragma unroll
-      for (int j = 0; j < FN; ++j)
-#pragma unroll
-        for (int tt = 0; tt < 2; ++tt) {
-          const int gnp = n0 + wc * WTN + j * 32 + tt * 16 + 4 * hi;      // packed column of the value quad
-          bval[j][tt] = ld128f(r_bias, gnp < p.n ? gnp * 4 : kInv);
-          bgate[j][tt] = ld128f(r_bias, gnp < p.n ? (gnp + 8) * 4 : kInv);
-        }
-      __syncthreads();                                 // all waves are done with the operand ring
-      TL(4);
-#pragma unroll
-      for (int i = 0; i < FM; ++i) {
-        const int mb = m0 + wr * WTM + i * 32;
-#pragma unroll
-        for (int jc = 0; jc < FN; jc += 2) {
-          const int nfr = (jc + 1 < FN) ? 2 : 1;
-#pragma unroll
-          for (int jj = 0; jj < 2; ++jj) {
-            if (jc + jj < FN) {
-#pragma unroll
-              for (int tt = 0; tt < 2; ++tt) {
-                const float4 bv = bval[jc + jj][tt], bg = bgate[jc + jj][tt];
-                const float bvv[4] = {bv.x, bv.y, bv.z, bv.w}, bgv[4] = {bg.x, bg.y, bg.z, bg.w};
-                float v[4];
-#pragma unroll
-                for (int e = 0; e < 4; ++e)
-                  v[e] = (acc[i][jc + jj][(2 * tt) * 4 + e] + bvv[e]) * gelu_erf_f(acc[i][jc + jj][(2 * tt + 1) * 4 + e] + bgv[e]);
-                *(float4*)(ebuf + strip_off(l31, jj * 4 + tt * 2 + hi, nfr * 4)) = make_float4(v[0], v[1], v[2], v[3]);
-              }
-            }
-          }
-          const int q_per_row = nfr * 4;               // output quads per strip row (16 output columns per fragment)
-          const int rows_per_pass = 64 / q_per_row;
-          const int qq = lane % q_per_row, rr = lane / q_per_row;
-          const int oc = ((n0 + wc * WTN + jc * 32) >> 1) + qq * 4;     // output column
-#pragma unroll
-          for (int pass = 0; pass < 4; ++pass) {
-            if (pass * rows_per_pass < 32) {
-              const int r = pass * rows_per_pass + rr;
-              const float4 t = *(const float4*)(ebuf + strip_off(r, qq, q_per_row));
-              const int gm = mb + r;
-              st64(r_out, (gm < p.m && oc * 2 < p.n) ? (int)(((long)gm * p.ldo + oc) * 2) : kInv,
-                   pack2<Tag>(t.x, t.y), pack2<Tag>(t.z, t.w));
-            }
-          }
-        }
-      }
-    }
-#ifdef TT_GEMM_TIMELINE
-    __builtin_amdgcn_s_waitcnt(0);
-    TL(5);
-#endif
-    return;
-  }
-  // direct path: fp32 output and the padded transposed output (never combined with split-K: see tt_gemm)
-#pragma unroll
-  for (int i = 0; i < FM; ++i) {
-    const int gm = m0 + wr * WTM + i * 32 + l31;
-    if (gm >= p.m) continue;
-#pragma unroll
-    for (int j = 0; j < FN; ++j) {
-      const int nb = n0 + wc * WTN + j * 32;
-#pragma unroll
-      for (int g = 0; g < 4; ++g) {
-        const int gn = nb + 8 * g + 4 * hi;
-        if (gn >= p.n) continue;
-        float v[4];
-#pragma unroll
-        for (int e = 0; e < 4; ++e) v[e] = acc[i][j][g * 4 + e];
-        epilogue_quad<Tag>(p, gm, gn, v);
-      }
-    }
-  }
-}
-
-// ---- (opt-in: tt_gemm_set_streaming_square / TT_GEMM_SQ320=1) square C = 320 linears of the finest UNet level (to_out /
-// to_q / proj_in / proj_out at 32x56 latents: ~60 launches per step, M = 50176).  Measured: 31 us against 36 us for the
-// tiled kernel in isolation, but 0.1-0.3 ms per step SLOWER inside the two-branch graph (one 160 KiB block per CU leaves
-// no room for the other branch's kernels), hence off by default.  The tiled kernel above needs 1.5 rounds of lock-stepped blocks for them and re-reads W from L2
-// for every tile (36-50 us against ~20 us for their 64-96 MB at HBM speed).  Here W never touches LDS: each of the 10
-// waves of a block keeps its 32 output columns x 320 K of W in registers (20 MFMA operands = 80 VGPRs) for the whole
-// launch, blocks are persistent over 32-row tiles of A, and LDS holds only a deep ring of A (and residual) tiles filled
-// by LDS-DMA, so the launch streams A / residual / out at HBM speed with several tiles in flight per CU.
-// Epilogue terms: bias, scale, residual, AlphaBlender with the residual as its source (the plain variant above).
-constexpr int SQ_K = 320, SQ_N = 320, SQ_ROWS = 32, SQ_WAVES = SQ_N / 32, SQ_NT = 64 * SQ_WAVES;
-constexpr int SQ_CPR = SQ_K / 8;                               // 16-byte chunks per tile row (40)
-constexpr int SQ_TILE_BYTES = SQ_ROWS * SQ_K * 2;              // 20 KiB: one A (or residual) tile
-constexpr int SQ_PASSES = SQ_ROWS * SQ_CPR / SQ_NT;            // DMA instructions per thread per tile (2)
-static_assert(SQ_ROWS * SQ_CPR % SQ_NT == 0 && SQ_CPR % 8 == 0, "sq320 staging");
-__device__ __forceinline__ int sq_swz(int row) { return (row >> 1) & 7; }     // 640-byte rows: see tile_swz
-__device__ __forceinline__ int sq_off(int row, int chunk) { return (row * SQ_CPR + (chunk ^ sq_swz(row))) << 4; }
-
-template <typename Tag, bool HAS_RES>
-__global__ __launch_bounds__(SQ_NT) void sq320_kernel(const GemmP p) {
-  extern __shared__ __attribute__((aligned(16))) char smem[];
-  constexpr int G = HAS_RES ? 2 * SQ_PASSES : SQ_PASSES;       // DMA instructions per thread per ring slot
-  constexpr int SLOT = HAS_RES ? 2 * SQ_TILE_BYTES : SQ_TILE_BYTES;
-  constexpr int NST = HAS_RES ? 3 : 5;                         // ring depth: 120 / 100 KiB + 40 KiB of strips
-  constexpr int KS = SQ_K / 16;
-  const int tid = threadIdx.x, lane = tid & 63;
-  const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int l31 = lane & 31, hi = lane >> 5;
-  const int ntiles = (p.m + SQ_ROWS - 1) / SQ_ROWS;
-  const int my_tiles = blockIdx.x < ntiles ? (ntiles - 1 - (int)blockIdx.x) / (int)gridDim.x + 1 : 0;
-  const __amdgpu_buffer_rsrc_t ra = make_rsrc(p.a0, p.a0_bytes);
-  const __amdgpu_buffer_rsrc_t rr = make_rsrc(p.residual, p.res_bytes);
-  const __amdgpu_buffer_rsrc_t rw = make_rsrc(p.w, p.w_bytes);
-
-  // ---- W operands of this wave's 32 columns: lane (column l31, k-half hi) holds k = ks*16 + hi*8 .. +8
-  uint4 wf[KS];
-  {
-    const int voff = (int)(((long)(wid * 32 + l31) * p.ldw + hi * 8) * 2);
-#pragma unroll
-    for (int ks = 0; ks < KS; ++ks) {
-      const u32x4_t v = __builtin_amdgcn_raw_buffer_load_b128(rw, voff, ks * 32, 0);
-      wf[ks] = make_uint4(v.x, v.y, v.z, v.w);
-    }
-  }
-  const int qq = lane & 7, rr_ = lane >> 3;                    // epilogue layout: 8 quads per 32-column row, 8 rows per pass
-  const int gn = wid * 32 + qq * 4;
-  const float4 b4 = ld128f(make_rsrc(p.bias, p.bias_bytes), gn * 4);
-  const float alpha = p.blend ? p.alpha : 0.0f, one_m_alpha = 1.0f - alpha;
-  const __amdgpu_buffer_rsrc_t r_out = make_rsrc(p.out, p.out_bytes);
-
-  // per-thread source offsets inside a tile (the tile's first row is a scalar offset)
-  int voa[SQ_PASSES], vor[SQ_PASSES], vrow[SQ_PASSES];
-#pragma unroll
-  for (int i = 0; i < SQ_PASSES; ++i) {
-    const int c = i * SQ_NT + tid, row = c / SQ_CPR, ch = (c % SQ_CPR) ^ sq_swz(row);
-    vrow[i] = row;
-    voa[i] = (int)(((long)row * p.lda0 + ch * 8) * 2);
-    vor[i] = (int)(((long)row * p.ld_res + ch * 8) * 2);
-  }
-  auto stage = [&](int j, int slot) {        // j-th tile of this block; beyond the end it still issues G (dropped) loads
-    // straight-line on purpose: with a branch around the DMA hipcc loses count of the loads in flight and drains them
-    // (vmcnt(0)) before every tile.  Past the last tile every row fails the bounds test, so nothing is fetched.
-    const int m0 = ((int)blockIdx.x + j * (int)gridDim.x) * SQ_ROWS;
-    char* la = smem + slot * SLOT + wid * 1024;
-    const int soa = __builtin_amdgcn_readfirstlane((int)((long)m0 * p.lda0 * 2));
-    const int sor = __builtin_amdgcn_readfirstlane((int)((long)m0 * p.ld_res * 2));
-#pragma unroll
-    for (int i = 0; i < SQ_PASSES; ++i)
-      __builtin_amdgcn_raw_ptr_buffer_load_lds(ra, (__attribute__((address_space(3))) void*)(la + i * (SQ_NT * 16)), 16,
-                                               m0 + vrow[i] < p.m ? voa[i] : kInv, soa, 0, 0);
-    if constexpr (HAS_RES) {
-#pragma unroll
-      for (int i = 0; i < SQ_PASSES; ++i)
-        __builtin_amdgcn_raw_ptr_buffer_load_lds(rr, (__attribute__((address_space(3))) void*)(la + SQ_TILE_BYTES + i * (SQ_NT * 16)), 16,
-                                                 m0 + vrow[i] < p.m ? vor[i] : kInv, sor, 0, 0);
-    }
-  };
-  const unsigned lds_base = lds_addr(smem);
-  const unsigned strip = lds_base + NST * SLOT + wid * 4096;    // 32 rows x 128 bytes (fp32 x 32 columns), swizzled
-  auto strip_off = [](int row, int quad) { return row * 128 + ((quad ^ (row & 7)) << 4); };
-
-  // one tile: `after` = VMEM instructions this thread issued after the DMA of tile j (all of them may stay in flight)
-  auto tile = [&](int j, int slot, int fill, auto after_tag) {
-    constexpr int AFTER = decltype(after_tag)::value;
-    wait_vmcnt<AFTER>();
-    __builtin_amdgcn_s_barrier();            // tile j visible to all waves; every wave is done with tile j-1's slot
-    asm volatile("" ::: "memory");
-    stage(j + NST - 1, fill);
-    const unsigned sa = lds_base + slot * SLOT;
-    f32x16_t acc;
-#pragma unroll
-    for (int r = 0; r < 16; ++r) acc[r] = 0.f;
-    // A fragments in batches of 2 (raw LDS reads, see lds_read16_raw): batch b+1 is in flight under batch b's MFMAs
-    constexpr int FB = 2, NB = KS / FB;
-    static_assert(KS % FB == 0, "fragment batches");
-    raw_u32x4_t af[2][FB];
-#pragma unroll
-    for (int f = 0; f < FB; ++f) af[0][f] = lds_read16_raw(sa + sq_off(l31, f * 2 + hi));
-#pragma unroll
-    for (int bt = 0; bt < NB; ++bt) {
-      if (bt + 1 < NB) {
-#pragma unroll
-        for (int f = 0; f < FB; ++f) af[(bt + 1) & 1][f] = lds_read16_raw(sa + sq_off(l31, ((bt + 1) * FB + f) * 2 + hi));
-        lds_wait<FB>();
-      } else {
-        lds_wait<0>();
-      }
-#pragma unroll
-      for (int f = 0; f < FB; ++f) {
-        const raw_u32x4_t a4 = af[bt & 1][f];
-        acc = Cvt<Tag>::mfma32(wf[bt * FB + f], make_uint4(a4.x, a4.y, a4.z, a4.w), acc);
-      }
-    }
-    // epilogue of the wave's 32 x 32 block: transpose through the strip, 4 passes of 8 rows x 64 bytes.
-    // The raw ds_write is invisible to hipcc's hazard recogniser: the MFMA results need their 18 wait states by hand.
-    __builtin_amdgcn_sched_barrier(0);
-    asm volatile("s_nop 15\n\ts_nop 15" ::: "memory");
-#pragma unroll
-    for (int g = 0; g < 4; ++g)
-      lds_write16_raw(strip + strip_off(l31, 2 * g + hi), acc[g * 4], acc[g * 4 + 1], acc[g * 4 + 2], acc[g * 4 + 3]);
-    const int m0 = ((int)blockIdx.x + j * (int)gridDim.x) * SQ_ROWS;
-    raw_u32x4_t tq[4];
-    raw_u32x2_t rq[4];
-#pragma unroll
-    for (int pass = 0; pass < 4; ++pass) {
-      const int r = pass * 8 + rr_;
-      tq[pass] = lds_read16_raw(strip + strip_off(r, qq));
-      rq[pass] = (raw_u32x2_t){0u, 0u};
-      if constexpr (HAS_RES) rq[pass] = lds_read8_raw(sa + SQ_TILE_BYTES + sq_off(r, gn >> 3) + (gn & 7) * 2);
-    }
-    lds_wait<0>();
-#pragma unroll
-    for (int pass = 0; pass < 4; ++pass) {
-      const int r = pass * 8 + rr_;
-      const float t4[4] = {__uint_as_float(tq[pass].x), __uint_as_float(tq[pass].y), __uint_as_float(tq[pass].z), __uint_as_float(tq[pass].w)};
-      float v[4], r4[4];
-      unpack4<Tag>(make_uint2(rq[pass].x, rq[pass].y), r4);
-      const float bb[4] = {b4.x, b4.y, b4.z, b4.w};
-#pragma unroll
-      for (int e = 0; e < 4; ++e) v[e] = alpha * r4[e] + one_m_alpha * ((t4[e] + bb[e]) * p.acc_scale + r4[e]);
-      const int gm = m0 + r;
-      st64(r_out, gm < p.m ? (int)(((long)gm * p.ldo + gn) * 2) : kInv, pack2<Tag>(v[0], v[1]), pack2<Tag>(v[2], v[3]));
-    }
-  };
-
-  // ---- ring: tiles 0 .. NST-2 in flight before the loop; iteration j waits for tile j and issues tile j+NST-1.
-  // VMEM instructions per iteration after its wait: G loads + 4 stores, hence the counts below.
-#pragma unroll
-  for (int s = 0; s < NST - 1; ++s) stage(s, s);
-  int slot = 0, fill = NST - 1;
-  auto advance = [&]() { slot = slot + 1 == NST ? 0 : slot + 1; fill = fill + 1 == NST ? 0 : fill + 1; };
-  int j = 0;
-  // first NST-1 iterations: fewer instructions separate a tile's DMA from its use
-  if (j < my_tiles) { tile(j, slot, fill, std::integral_constant<int, (NST - 2) * G>{}); advance(); ++j; }
-  if (j < my_tiles) { tile(j, slot, fill, std::integral_constant<int, (NST - 3 > 0 ? NST - 3 : 0) * G + (G + 4)>{}); advance(); ++j; }
-  if constexpr (NST > 3) {
-    if (j < my_tiles) { tile(j, slot, fill, std::integral_constant<int, (NST - 4 > 0 ? NST - 4 : 0) * G + 2 * (G + 4)>{}); advance(); ++j; }
-    if (j < my_tiles) { tile(j, slot, fill, std::integral_constant<int, (NST - 5 > 0 ? NST - 5 : 0) * G + 3 * (G + 4)>{}); advance(); ++j; }
-  }
-  for (; j < my_tiles; ++j) { tile(j, slot, fill, std::integral_constant<int, 4 + (NST - 2) * (G + 4)>{}); advance(); }
-}
-
-// split-K second pass: sum the fp32 slabs in a fixed order (bit-reproducible) and run the normal epilogue
-template <typename Tag>
-__global__ __launch_bounds__(256) void splitk_epilogue_kernel(const GemmP p) {
-  const long quads = (long)p.m * (p.n >> 2);
-  const int nq = p.n >> 2;
-  for (long q = (long)blockIdx.x * blockDim.x + threadIdx.x; q < quads; q += (long)gridDim.x * blockDim.x) {
-    const int gm = (int)(q / nq), gn = (int)(q - (long)gm * nq) * 4;
-    float4 a = *(const float4*)(p.ws + (long)gm * p.n + gn);
-    for (int s2 = 1; s2 < p.splitk; ++s2) {
-      const float4 b = *(const float4*)(p.ws + ((long)s2 * p.m + gm) * p.n + gn);
-      a.x += b.x; a.y += b.y; a.z += b.z; a.w += b.w;
-    }
-    float v[4] = {a.x, a.y, a.z, a.w};
-    epilogue_quad<Tag>(p, gm, gn, v);
-  }
-}
-
-// ---- configurations: {BM, BN, BK, NST, WGM, WGN}
-template <typename Tag, int BM, int BN, int BK, int NST, int WGM, int WGN, int MODE>
-void launch_mode(const GemmP& p, hipStream_t st) {
-  constexpr int NT_ = 64 * WGM * WGN, CPR_ = BK / 8;
-  constexpr size_t lds = (size_t)NST * (((BM * CPR_ + NT_ - 1) / NT_) + ((BN * CPR_ + NT_ - 1) / NT_)) * NT_ * 16;
-  static_assert(lds <= 160 * 1024, "LDS ring exceeds 160 KiB");
-  static unsigned long long attr_done = 0;     // per kernel instance, one bit per device (see tt_lds_opt_in)
-  tt_lds_opt_in((const void*)gemm_kernel<Tag, BM, BN, BK, NST, WGM, WGN, MODE>, (int)lds, &attr_done);
-  hipLaunchKernelGGL((gemm_kernel<Tag, BM, BN, BK, NST, WGM, WGN, MODE>), dim3(p.tiles_m * p.tiles_n * p.splitk),
-                     dim3(64 * WGM * WGN), lds, st, p);
-  if (p.splitk > 1) {
-    long blocks = ((long)p.m * (p.n >> 2) + 255) / 256;
-    if (blocks > 2048) blocks = 2048;
-    hipLaunchKernelGGL(splitk_epilogue_kernel<Tag>, dim3((unsigned)blocks), dim3(256), 0, st, p);
-  }
-}
-
-template <typename Tag, int BM, int BN, int BK, int NST, int WGM, int WGN>
-void launch_cfg(GemmP& p, hipStream_t st) {
-  p.tiles_m = ceil_div(p.m, BM);
-  p.tiles_n = ceil_div(p.n, BN);
-  p.nk0 = ceil_div(p.k0, BK); p.nk1 = p.k1 ? ceil_div(p.k1, BK) : 0;
-  p.kt_total = p.taps * (p.nk0 + p.nk1);
-  switch (p.mode) {
-    case 0: launch_mode<Tag, BM, BN, BK, NST, WGM, WGN, 0>(p, st); break;
-    case 1: launch_mode<Tag, BM, BN, BK, NST, WGM, WGN, 1>(p, st); break;
-    default: launch_mode<Tag, BM, BN, BK, NST, WGM, WGN, 2>(p, st); break;
-  }
-}
-
 struct TileCfg { int bm, bn, bk, nst, wgm, wgn; };
-constexpr TileCfg kCfgs[] = {
-  {128, 128, 64, 2, 2, 2},   // 0: round-1 baseline (64 KiB, 2 blocks/CU)
+constexpr TileCfg kCfgs[] = {        // keep in step with launch<Tag>() in gemm_kernel.h
+  {128, 128, 64, 2, 2, 2},   // 0: 4 waves, 64 KiB, 2 blocks/CU
   {128,  64, 64, 3, 2, 2},   // 1: 72 KiB
   { 64,  64, 64, 4, 2, 2},   // 2: small problems, deep ring (64 KiB)
   {256, 128, 32, 3, 4, 2},   // 3: 8 waves, 72 KiB -> 2 blocks/CU
   {256, 256, 32, 3, 2, 4},   // 4: 8 waves, 96 KiB
-  {256, 256, 32, 4, 2, 4},   // 5: 8 waves, 128 KiB
-  {128, 128, 32, 3, 2, 2},   // 6: 48 KiB -> 3 blocks/CU
-  {128, 128, 32, 4, 2, 2},   // 7: 64 KiB -> 2 blocks/CU
-  {256, 128, 64, 3, 4, 2},   // 8: 8 waves, 144 KiB
-  {128, 128, 64, 3, 2, 2},   // 9: 96 KiB, 1 block/CU
-  {128, 160, 64, 2, 4, 1},   // 10: N = 320 without tile waste, wave tile 32x160, 72 KiB
-  {128, 160, 32, 3, 4, 1},   // 11: 54 KiB
-  {128, 320, 32, 3, 4, 2},   // 12: 8 waves, wave tile 32x160, 84 KiB
-  {256, 320, 32, 3, 4, 2},   // 13: 8 waves, wave tile 64x160, 108 KiB
-  {256, 256, 64, 2, 2, 4},   // 14: 8 waves, wave tile 128x64, 128 KiB, plain double buffer
-  {256, 128, 64, 2, 4, 2},   // 15: 8 waves, 96 KiB, plain double buffer
-  {128, 128, 64, 4, 2, 2},   // 16: 128 KiB, 1 block/CU, prefetch distance 3
-  {128, 128, 32, 5, 2, 2},   // 17: 80 KiB, 2 blocks/CU, prefetch distance 4 (x32)
-  {128, 128, 64, 2, 4, 2},   // 18: 8 waves (wave tile 32x64), 64 KiB -> 16 waves/CU
-  {128, 128, 32, 2, 2, 2},   // 19: 4 waves, 32 KiB
-  {256, 160, 32, 3, 8, 1},   // 20: N = 320/960, 8 waves (wave tile 32x160), 78 KiB -> 2 blocks/CU
-  {256, 128, 32, 4, 4, 2},   // 21: like 3 with one more stage (96 KiB, 1 block/CU)
-  {128, 128, 32, 4, 4, 2},   // 22: 8 waves, 64 KiB, prefetch distance 3 (x32) -> 2 blocks/CU
-  {128, 128, 32, 5, 4, 2},   // 23: 8 waves, 80 KiB, prefetch distance 4 (x32) -> 2 blocks/CU
-  {128, 128, 64, 3, 4, 2},   // 24: 8 waves, 96 KiB, prefetch distance 2 -> 1 block/CU
-  {128, 128, 64, 4, 4, 2},   // 25: 8 waves, 128 KiB, prefetch distance 3 -> 1 block/CU
+  {128, 128, 32, 3, 2, 2},   // 5: 48 KiB -> 3 blocks/CU
+  {256, 128, 64, 3, 4, 2},   // 6: 8 waves, 144 KiB
+  {128, 160, 64, 2, 4, 1},   // 7: N = 320 without tile waste, wave tile 32x160, 72 KiB
+  {128, 320, 32, 3, 4, 2},   // 8: 8 waves, wave tile 32x160, 84 KiB
+  {256, 256, 64, 2, 2, 4},   // 9: 8 waves, wave tile 128x64, 128 KiB, plain double buffer
+  {128, 128, 64, 4, 2, 2},   // 10: 128 KiB, 1 block/CU, prefetch distance 3
+  {128, 128, 64, 2, 4, 2},   // 11: 8 waves (wave tile 32x64), 64 KiB -> 16 waves/CU
+  {256, 160, 32, 3, 8, 1},   // 12: N = 320/960, 8 waves (wave tile 32x160), 78 KiB -> 2 blocks/CU
+  {256, 128, 32, 4, 4, 2},   // 13: like 3 with one more stage (96 KiB, 1 block/CU)
+  {128, 128, 32, 5, 4, 2},   // 14: 8 waves, 80 KiB, prefetch distance 4 (x32) -> 2 blocks/CU
+  {128, 128, 64, 3, 4, 2},   // 15: 8 waves, 96 KiB, prefetch distance 2 -> 1 block/CU
+  {128, 128, 64, 4, 4, 2},   // 16: 8 waves, 128 KiB, prefetch distance 3 -> 1 block/CU
 };
 constexpr int kNumCfgs = sizeof(kCfgs) / sizeof(kCfgs[0]);
 
@@ -909,10 +78,10 @@ Plan make_plan(int m, int n, long ktot, bool allow_split, bool wide_ok = true) {
   const long b128 = (long)ceil_div(m, 128) * ceil_div(n, 128);
   const long b12864 = (long)ceil_div(m, 128) * ceil_div(n, 64);
   if (f >= 0 && f < kNumCfgs) pl.cfg = f;
-  else if (n % 160 == 0 && n % 128 != 0 && n <= 960 && m >= 2048) pl.cfg = 10;
+  else if (n % 160 == 0 && n % 128 != 0 && n <= 960 && m >= 2048) pl.cfg = 7;
   else if (m >= 8192 && n >= 1024 && wide_ok) pl.cfg = 3;
-  else if (m < 2048 && n >= 2560 && n % 160 == 0) pl.cfg = 10;
-  else if (b128 >= 384) pl.cfg = 18;                 // 128x128 with 8 waves (32x64 wave tiles): 16 waves per CU
+  else if (m < 2048 && n >= 2560 && n % 160 == 0) pl.cfg = 7;
+  else if (b128 >= 384) pl.cfg = 11;                 // 128x128 with 8 waves (32x64 wave tiles): 16 waves per CU
   else if (b12864 >= 384) pl.cfg = 1;
   else pl.cfg = 2;
   const int fs = forced_split();
@@ -923,7 +92,7 @@ Plan make_plan(int m, int n, long ktot, bool allow_split, bool wide_ok = true) {
   if (deep && f < 0 && b128 <= 256 && ktot > 0) {
     // at most one 128x128 tile per CU: LDS is free for a 4-deep ring (prefetch distance 3), which beats two resident
     // blocks with a double buffer once the loads really overlap the MFMAs; K is split only as far as whole CUs are idle
-    pl.cfg = 25;
+    pl.cfg = 16;
     long s = allow_split ? 256 / b128 : 1;
     if (s > kt / 8) s = kt / 8;
     if (s > 16) s = 16;
@@ -934,48 +103,16 @@ Plan make_plan(int m, int n, long ktot, bool allow_split, bool wide_ok = true) {
     long s = (512 + b128 - 1) / b128;
     if (s > kt / 8) s = kt / 8;
     if (s > 16) s = 16;
-    if (s >= 2) { pl.cfg = 18; pl.splitk = (int)s; }
+    if (s >= 2) { pl.cfg = 11; pl.splitk = (int)s; }
   }
   return pl;
 }
 
-template <typename Tag>
-void launch(GemmP& p, int cfg, hipStream_t st) {
-  switch (cfg) {
-    case 0: launch_cfg<Tag, 128, 128, 64, 2, 2, 2>(p, st); break;
-    case 1: launch_cfg<Tag, 128, 64, 64, 3, 2, 2>(p, st); break;
-    case 2: launch_cfg<Tag, 64, 64, 64, 4, 2, 2>(p, st); break;
-    case 3: launch_cfg<Tag, 256, 128, 32, 3, 4, 2>(p, st); break;
-    case 4: launch_cfg<Tag, 256, 256, 32, 3, 2, 4>(p, st); break;
-    case 5: launch_cfg<Tag, 256, 256, 32, 4, 2, 4>(p, st); break;
-    case 6: launch_cfg<Tag, 128, 128, 32, 3, 2, 2>(p, st); break;
-    case 7: launch_cfg<Tag, 128, 128, 32, 4, 2, 2>(p, st); break;
-    case 8: launch_cfg<Tag, 256, 128, 64, 3, 4, 2>(p, st); break;
-    case 9: launch_cfg<Tag, 128, 128, 64, 3, 2, 2>(p, st); break;
-    case 10: launch_cfg<Tag, 128, 160, 64, 2, 4, 1>(p, st); break;
-    case 11: launch_cfg<Tag, 128, 160, 32, 3, 4, 1>(p, st); break;
-    case 12: launch_cfg<Tag, 128, 320, 32, 3, 4, 2>(p, st); break;
-    case 13: launch_cfg<Tag, 256, 320, 32, 3, 4, 2>(p, st); break;
-    case 14: launch_cfg<Tag, 256, 256, 64, 2, 2, 4>(p, st); break;
-    case 15: launch_cfg<Tag, 256, 128, 64, 2, 4, 2>(p, st); break;
-    case 16: launch_cfg<Tag, 128, 128, 64, 4, 2, 2>(p, st); break;
-    case 17: launch_cfg<Tag, 128, 128, 32, 5, 2, 2>(p, st); break;
-    case 18: launch_cfg<Tag, 128, 128, 64, 2, 4, 2>(p, st); break;
-    case 19: launch_cfg<Tag, 128, 128, 32, 2, 2, 2>(p, st); break;
-    case 20: launch_cfg<Tag, 256, 160, 32, 3, 8, 1>(p, st); break;
-    case 21: launch_cfg<Tag, 256, 128, 32, 4, 4, 2>(p, st); break;
-    case 22: launch_cfg<Tag, 128, 128, 32, 4, 4, 2>(p, st); break;
-    case 23: launch_cfg<Tag, 128, 128, 32, 5, 4, 2>(p, st); break;
-    case 24: launch_cfg<Tag, 128, 128, 64, 3, 4, 2>(p, st); break;
-    default: launch_cfg<Tag, 128, 128, 64, 4, 4, 2>(p, st); break;
-  }
-}
+constexpr TileCfg kCfgsF32[] = {{128, 128, 32, 2, 2, 2}, {64, 64, 32, 4, 2, 2}};
+int plan_f32(int m, int n) { return (long)ceil_div(m, 128) * ceil_div(n, 128) >= 256 ? 0 : 1; }
 
 }  // namespace
 
-#ifdef TT_GEMM_TIMELINE
-extern "C" int tt_debug_timeline(long long* host, int n) { return (int)hipMemcpyFromSymbol(host, HIP_SYMBOL(g_tl), n * 8); }
-#endif
 
 extern "C" int tt_gemm_set_tile_override(int32_t cfg) {
   if (cfg < -1 || cfg >= kNumCfgs) TT_FAIL(TT_EINVAL, "tt_gemm_set_tile_override: cfg %d (valid -1..%d)", cfg, kNumCfgs - 1);
@@ -991,21 +128,12 @@ extern "C" int tt_gemm_set_streaming_square(int32_t on) {
 
 bool sq320_ok(const TtGemmArgs* a) {
   if (g_sq320 < 0) { const char* e = getenv("TT_GEMM_SQ320"); g_sq320 = e ? atoi(e) : 0; }
-  return g_sq320 && forced_cfg() < 0 && a->mode == 0 && a->k1 == 0 && a->k0 == SQ_K && a->n == SQ_N && a->m >= 4096 &&
+  return g_sq320 && a->dtype != TT_F32 && forced_cfg() < 0 && a->mode == 0 && a->k1 == 0 && a->k0 == SQ_K && a->n == SQ_N && a->m >= 4096 &&
          !a->geglu && !a->rowvec && !a->out_f32 && !a->out_col_hw &&
          (!a->blend || (a->blend == a->residual && a->ld_blend == a->ld_res));
 }
-template <typename Tag, bool HAS_RES>
-void launch_sq320(const GemmP& p, hipStream_t st) {
-  constexpr size_t lds = (size_t)(HAS_RES ? 3 * 2 * SQ_TILE_BYTES : 5 * SQ_TILE_BYTES) + SQ_WAVES * 4096;
-  static_assert(lds <= 160 * 1024, "sq320 LDS");
-  static unsigned long long attr_done = 0;
-  tt_lds_opt_in((const void*)sq320_kernel<Tag, HAS_RES>, (int)lds, &attr_done);
-  const int ntiles = (p.m + SQ_ROWS - 1) / SQ_ROWS;
-  hipLaunchKernelGGL((sq320_kernel<Tag, HAS_RES>), dim3(ntiles < 256 ? ntiles : 256), dim3(SQ_NT), lds, st, p);
-}
-
 static Plan plan_for(const TtGemmArgs* a) {
+  if (a->dtype == TT_F32) return Plan{plan_f32(a->m, a->n), 1};
   const int taps = a->mode == 1 ? 9 : (a->mode == 2 ? 3 : 1);
   const bool allow = !a->geglu;
   return make_plan(a->m, a->n, (long)taps * (a->k0 + a->k1), allow, !(a->residual || a->blend || a->rowvec));
@@ -1021,7 +149,7 @@ extern "C" int tt_gemm_plan(const TtGemmArgs* a, int32_t cfg[7]) {
   if (pl.splitk > 1 && (!a->ws || (size_t)a->ws_bytes < (size_t)pl.splitk * a->m * a->n * sizeof(float) ||
                         (long)pl.splitk * a->m * a->n * 4 >= (1L << 31)))
     pl = Plan{make_plan(a->m, a->n, 0, false, !(a->residual || a->blend || a->rowvec)).cfg, 1};
-  const TileCfg& t = kCfgs[pl.cfg];
+  const TileCfg& t = a->dtype == TT_F32 ? kCfgsF32[pl.cfg] : kCfgs[pl.cfg];
   cfg[0] = t.bm; cfg[1] = t.bn; cfg[2] = t.bk; cfg[3] = t.nst; cfg[4] = t.wgm; cfg[5] = t.wgn; cfg[6] = pl.splitk;
   return TT_OK;
 }
@@ -1035,11 +163,11 @@ extern "C" size_t tt_gemm_ws_bytes(const TtGemmArgs* a) {
 extern "C" int tt_gemm(const TtGemmArgs* a, tt_stream_t stream) {
   if (!a || !a->a0 || !a->w || !a->out) TT_FAIL(TT_EINVAL, "tt_gemm: null operand");
   if (a->m <= 0 || a->n <= 0 || a->k0 <= 0) TT_FAIL(TT_EINVAL, "tt_gemm: empty problem m=%d n=%d k0=%d", a->m, a->n, a->k0);
+  if (a->dtype != TT_BF16 && a->dtype != TT_F16 && a->dtype != TT_F32) TT_FAIL(TT_EINVAL, "tt_gemm: bad dtype");
   if ((a->k0 & 7) || (a->k1 & 7) || (a->n & 3)) TT_FAIL(TT_EINVAL, "tt_gemm: k0/k1 must be multiples of 8 and n of 4");
   if ((a->lda0 & 7) || (a->k1 && (a->lda1 & 7)) || (a->ldw & 7)) TT_FAIL(TT_EINVAL, "tt_gemm: row strides must be multiples of 8 elements");
   if (a->k1 && !a->a1) TT_FAIL(TT_EINVAL, "tt_gemm: k1 > 0 without a1");
   if (a->mode < 0 || a->mode > 2) TT_FAIL(TT_EINVAL, "tt_gemm: bad mode %d", a->mode);
-  if (a->dtype != TT_BF16 && a->dtype != TT_F16) TT_FAIL(TT_EINVAL, "tt_gemm: bad dtype");
   if (a->geglu && ((a->n & 15) || a->residual || a->blend || a->rowvec || a->out_f32 || a->out_col_hw))
     TT_FAIL(TT_EINVAL, "tt_gemm: geglu needs n %% 16 == 0 and no other epilogue terms");
   if (a->rowvec && a->rowvec_rows <= 0) TT_FAIL(TT_EINVAL, "tt_gemm: rowvec_rows");
@@ -1053,7 +181,8 @@ extern "C" int tt_gemm(const TtGemmArgs* a, tt_stream_t stream) {
   p.rowvec = a->rowvec; p.rowvec_rows = a->rowvec_rows; p.ld_rowvec = a->ld_rowvec;
   p.geglu = a->geglu; p.residual = (const char*)a->residual; p.ld_res = a->ld_res;
   p.blend = (const char*)a->blend; p.ld_blend = a->ld_blend; p.alpha = a->alpha;
-  p.out = (char*)a->out; p.ldo = a->ldo; p.out_f32 = a->out_f32;
+  const int es = a->dtype == TT_F32 ? 4 : 2;         // bytes per stored element
+  p.out = (char*)a->out; p.ldo = a->ldo; p.out_f32 = a->dtype == TT_F32 ? 0 : a->out_f32;   // TT_F32 stores fp32 anyway
   p.out_col_hw = a->out_col_hw; p.out_col_hwp = a->out_col_hwp;
   if (p.mode == 1) {
     if (p.nimg <= 0 || p.hin <= 0 || p.win <= 0 || p.hout <= 0 || p.wout <= 0 || p.stride < 1)
@@ -1066,16 +195,16 @@ extern "C" int tt_gemm(const TtGemmArgs* a, tt_stream_t stream) {
   p.taps = p.mode == 1 ? 9 : (p.mode == 2 ? 3 : 1);
   {
     const long rows = p.mode == 1 ? (long)p.nimg * p.hin * p.win : (long)p.m;
-    const long a0b = ((rows - 1) * p.lda0 + p.k0) * 2, a1b = p.k1 ? ((rows - 1) * p.lda1 + p.k1) * 2 : 16;
-    const long wb = ((long)(p.n - 1) * p.ldw + (long)p.taps * (p.k0 + p.k1)) * 2;
+    const long a0b = ((rows - 1) * p.lda0 + p.k0) * es, a1b = p.k1 ? ((rows - 1) * p.lda1 + p.k1) * es : 16;
+    const long wb = ((long)(p.n - 1) * p.ldw + (long)p.taps * (p.k0 + p.k1)) * es;
     if (a0b >= (1L << 31) || a1b >= (1L << 31) || wb >= (1L << 31))
       TT_FAIL(TT_EUNSUPPORTED, "tt_gemm: operand larger than 2 GiB (32-bit buffer offsets)");
     p.a0_bytes = (unsigned)a0b; p.a1_bytes = (unsigned)a1b; p.w_bytes = (unsigned)wb;
     // epilogue operands (bounds-checked descriptors; 0 bytes = absent -> loads return 0)
     const long n_out = p.geglu ? p.n / 2 : p.n;
-    const long outb = ((long)(p.m - 1) * p.ldo + (p.out_col_hw > 0 ? p.ldo : n_out)) * (p.out_f32 ? 4 : 2);
-    const long resb = p.residual ? ((long)(p.m - 1) * p.ld_res + p.n) * 2 : 0;
-    const long blb = p.blend ? ((long)(p.m - 1) * p.ld_blend + p.n) * 2 : 0;
+    const long outb = ((long)(p.m - 1) * p.ldo + (p.out_col_hw > 0 ? p.ldo : n_out)) * (p.out_f32 ? 4 : es);
+    const long resb = p.residual ? ((long)(p.m - 1) * p.ld_res + p.n) * es : 0;
+    const long blb = p.blend ? ((long)(p.m - 1) * p.ld_blend + p.n) * es : 0;
     const long rvb = p.rowvec ? ((long)((p.m - 1) / p.rowvec_rows) * p.ld_rowvec + p.n) * 4 : 0;
     if (outb >= (1L << 31) || resb >= (1L << 31) || blb >= (1L << 31) || rvb >= (1L << 31))
       TT_FAIL(TT_EUNSUPPORTED, "tt_gemm: epilogue operand larger than 2 GiB (32-bit buffer offsets)");
@@ -1085,8 +214,7 @@ extern "C" int tt_gemm(const TtGemmArgs* a, tt_stream_t stream) {
   hipStream_t st = (hipStream_t)stream;
   if (sq320_ok(a)) {
     p.splitk = 1; p.ws = nullptr; p.ws_bytes = 0;
-    if (a->dtype == TT_BF16) { if (p.residual) launch_sq320<bf16_tag, true>(p, st); else launch_sq320<bf16_tag, false>(p, st); }
-    else { if (p.residual) launch_sq320<f16_tag, true>(p, st); else launch_sq320<f16_tag, false>(p, st); }
+    if (a->dtype == TT_BF16) launch_sq320_bf16(p, st); else launch_sq320_f16(p, st);
     TT_CHECK_LAUNCH("tt_gemm");
     return TT_OK;
   }
@@ -1098,7 +226,9 @@ extern "C" int tt_gemm(const TtGemmArgs* a, tt_stream_t stream) {
   p.splitk = pl.splitk;
   p.ws = (float*)a->ws;
   p.ws_bytes = pl.splitk > 1 ? (unsigned)((long)pl.splitk * a->m * a->n * 4) : 0u;
-  if (a->dtype == TT_BF16) launch<bf16_tag>(p, pl.cfg, st); else launch<f16_tag>(p, pl.cfg, st);
+  if (a->dtype == TT_BF16) launch_bf16(p, pl.cfg, st);
+  else if (a->dtype == TT_F16) launch_f16(p, pl.cfg, st);
+  else launch_f32(p, pl.cfg, st);
   TT_CHECK_LAUNCH("tt_gemm");
   return TT_OK;
 }

@@ -36,25 +36,23 @@ __global__ void gn_partial_kernel(const char* x0, int c0, const char* x1, int c1
     const int ch = myv * 8;
     const char* base; long ld; int coff;
     if (ch < c0) { base = x0; ld = c0; coff = ch; } else { base = x1; ld = c1; coff = ch - c0; }
-    // 4 independent 16-byte loads in flight per thread (the kernel is a pure HBM stream)
-    const char* pbase = base + (((long)img * hw) * ld + coff) * 2;
-    const long rstride = ld * 2;
+    constexpr int ES = Elem<Tag>::ES;
+    const char* pbase = base + (((long)img * hw) * ld + coff) * ES;
+    const long rstride = ld * ES;
     int r = r0 + myr;
     for (; r + 3 * rpb < r1; r += 4 * rpb) {
-      uint4 v[4];
+      float f[4][8];                 // 4 independent row loads in flight per thread (the kernel is a pure HBM stream)
 #pragma unroll
-      for (int k = 0; k < 4; ++k) v[k] = *(const uint4*)(pbase + (long)(r + k * rpb) * rstride);
+      for (int k = 0; k < 4; ++k) load8<Tag>(pbase + (long)(r + k * rpb) * rstride, f[k]);
 #pragma unroll
       for (int k = 0; k < 4; ++k) {
-        float f[8];
-        unpack8<Tag>(v[k], f);
 #pragma unroll
-        for (int e = 0; e < 8; ++e) { s[e] += f[e]; q[e] = fmaf(f[e], f[e], q[e]); }
+        for (int e = 0; e < 8; ++e) { s[e] += f[k][e]; q[e] = fmaf(f[k][e], f[k][e], q[e]); }
       }
     }
     for (; r < r1; r += rpb) {
       float f[8];
-      unpack8<Tag>(*(const uint4*)(pbase + (long)r * rstride), f);
+      load8<Tag>(pbase + (long)r * rstride, f);
 #pragma unroll
       for (int e = 0; e < 8; ++e) { s[e] += f[e]; q[e] = fmaf(f[e], f[e], q[e]); }
     }
@@ -127,9 +125,10 @@ __global__ void gn_apply_kernel(const char* x0, int c0, const char* x1, int c1, 
     const long row = v / cv;
     const int ch = (int)(v - row * cv) * 8;
     const int img = (int)(row / hw);
-    const char* src = ch < c0 ? x0 + (row * c0 + ch) * 2 : x1 + (row * c1 + (ch - c0)) * 2;
+    constexpr int ES = Elem<Tag>::ES;
+    const char* src = ch < c0 ? x0 + (row * c0 + ch) * ES : x1 + (row * c1 + (ch - c0)) * ES;
     float f[8];
-    unpack8<Tag>(*(const uint4*)src, f);
+    load8<Tag>(src, f);
     const float4 s0 = *(const float4*)(scale + (long)img * C + ch), s1 = *(const float4*)(scale + (long)img * C + ch + 4);
     const float4 h0 = *(const float4*)(shift + (long)img * C + ch), h1 = *(const float4*)(shift + (long)img * C + ch + 4);
     const float sc[8] = {s0.x, s0.y, s0.z, s0.w, s1.x, s1.y, s1.z, s1.w};
@@ -139,7 +138,7 @@ __global__ void gn_apply_kernel(const char* x0, int c0, const char* x1, int c1, 
       float t = fmaf(f[e], sc[e], sh[e]);
       f[e] = silu ? silu_f(t) : t;
     }
-    *(uint4*)(y + (row * ldy + ch) * 2) = pack8<Tag>(f);
+    store8<Tag>(y + (row * ldy + ch) * ES, f);
   }
 }
 
@@ -159,11 +158,11 @@ __global__ __launch_bounds__(256) void ln_kernel(const char* x, long ldx, int ro
   for (int i = 0; i < MAXV; ++i) {
     const int vi = lane + i * 64;
     if (vi < cv) {
-      unpack8<Tag>(*(const uint4*)(x + ((long)row * ldx + vi * 8) * 2), v[i]);
+      load8<Tag>(x + ((long)row * ldx + vi * 8) * Elem<Tag>::ES, v[i]);
       if (rv) {
 #pragma unroll
-        for (int e = 0; e < 8; ++e) v[i][e] += rv[vi * 8 + e];
-        *(uint4*)(xsum + ((long)row * ldx + vi * 8) * 2) = pack8<Tag>(v[i]);
+        for (int e = 0; e < 8; ++e) v[i][e] = round_store<Tag>(v[i][e] + rv[vi * 8 + e]);   // normalise what xsum stores
+        store8<Tag>(xsum + ((long)row * ldx + vi * 8) * Elem<Tag>::ES, v[i]);
       }
 #pragma unroll
       for (int e = 0; e < 8; ++e) s += v[i][e];
@@ -191,7 +190,7 @@ __global__ __launch_bounds__(256) void ln_kernel(const char* x, long ldx, int ro
       float o8[8];
 #pragma unroll
       for (int e = 0; e < 8; ++e) o8[e] = (v[i][e] - mean) * rstd * gamma[vi * 8 + e] + beta[vi * 8 + e];
-      *(uint4*)(y + ((long)row * ldy + vi * 8) * 2) = pack8<Tag>(o8);
+      store8<Tag>(y + ((long)row * ldy + vi * 8) * Elem<Tag>::ES, o8);
     }
   }
 }
@@ -214,7 +213,7 @@ extern "C" int tt_groupnorm_stats(const void* x0, int32_t c0, const void* x1, in
   if (nimg <= 0 || hw <= 0 || C <= 0 || (C % GN_GROUPS) || (c0 & 7) || (c1 & 7)) TT_FAIL(TT_EINVAL, "tt_groupnorm_stats: C=%d+%d must be a multiple of 32, sources of 8", c0, c1);
   if (fpg <= 0 || nimg % fpg) TT_FAIL(TT_EINVAL, "tt_groupnorm_stats: frames_per_group %d does not divide %d images", fpg, nimg);
   if (ws_bytes < tt_groupnorm_ws_bytes(nimg, hw, C)) TT_FAIL(TT_EINVAL, "tt_groupnorm_stats: workspace too small");
-  if (dtype != TT_BF16 && dtype != TT_F16) TT_FAIL(TT_EINVAL, "tt_groupnorm_stats: bad dtype");
+  if (dtype != TT_BF16 && dtype != TT_F16 && dtype != TT_F32) TT_FAIL(TT_EINVAL, "tt_groupnorm_stats: bad dtype");
   const int cv = C >> 3;
   if (cv > 1024) TT_FAIL(TT_EUNSUPPORTED, "tt_groupnorm_stats: C=%d too wide", C);
   const int rows_per_chunk = gn_rows_per_chunk(C);
@@ -226,8 +225,10 @@ extern "C" int tt_groupnorm_stats(const void* x0, int32_t c0, const void* x1, in
   const size_t lds = (size_t)2 * rpb * C * sizeof(float);
   if (dtype == TT_BF16)
     hipLaunchKernelGGL(gn_partial_kernel<bf16_tag>, dim3(chunks, nimg), dim3(threads), lds, st, (const char*)x0, c0, (const char*)x1, c1, hw, chunks, (double*)ws);
-  else
+  else if (dtype == TT_F16)
     hipLaunchKernelGGL(gn_partial_kernel<f16_tag>, dim3(chunks, nimg), dim3(threads), lds, st, (const char*)x0, c0, (const char*)x1, c1, hw, chunks, (double*)ws);
+  else
+    hipLaunchKernelGGL(gn_partial_kernel<f32_tag>, dim3(chunks, nimg), dim3(threads), lds, st, (const char*)x0, c0, (const char*)x1, c1, hw, chunks, (double*)ws);
   hipLaunchKernelGGL(gn_finalize_kernel, dim3(nimg / fpg), dim3(32 * GN_SLICES), 0, st, (const double*)ws, chunks, hw, C, fpg, gamma, beta, eps, scale, shift);
   TT_CHECK_LAUNCH("tt_groupnorm_stats");
   return TT_OK;
@@ -240,14 +241,16 @@ extern "C" int tt_groupnorm_apply(const void* x0, int32_t c0, const void* x1, in
   if (!x0 || !scale || !shift || !y) TT_FAIL(TT_EINVAL, "tt_groupnorm_apply: null operand");
   if (c1 && !x1) TT_FAIL(TT_EINVAL, "tt_groupnorm_apply: c1 without x1");
   if ((c0 & 7) || (c1 & 7) || (ldy & 7) || ldy < C) TT_FAIL(TT_EINVAL, "tt_groupnorm_apply: channel counts/stride must be multiples of 8");
-  if (dtype != TT_BF16 && dtype != TT_F16) TT_FAIL(TT_EINVAL, "tt_groupnorm_apply: bad dtype");
+  if (dtype != TT_BF16 && dtype != TT_F16 && dtype != TT_F32) TT_FAIL(TT_EINVAL, "tt_groupnorm_apply: bad dtype");
   const long total = (long)nimg * hw * (C >> 3);
   long blocks = (total + 255) / 256; if (blocks > 4096) blocks = 4096;
   hipStream_t st = (hipStream_t)stream;
   if (dtype == TT_BF16)
     hipLaunchKernelGGL(gn_apply_kernel<bf16_tag>, dim3((unsigned)blocks), dim3(256), 0, st, (const char*)x0, c0, (const char*)x1, c1, hw, total, scale, shift, silu, (char*)y, (long)ldy);
-  else
+  else if (dtype == TT_F16)
     hipLaunchKernelGGL(gn_apply_kernel<f16_tag>, dim3((unsigned)blocks), dim3(256), 0, st, (const char*)x0, c0, (const char*)x1, c1, hw, total, scale, shift, silu, (char*)y, (long)ldy);
+  else
+    hipLaunchKernelGGL(gn_apply_kernel<f32_tag>, dim3((unsigned)blocks), dim3(256), 0, st, (const char*)x0, c0, (const char*)x1, c1, hw, total, scale, shift, silu, (char*)y, (long)ldy);
   TT_CHECK_LAUNCH("tt_groupnorm_apply");
   return TT_OK;
 }
@@ -259,13 +262,14 @@ extern "C" int tt_layernorm(const void* x, int64_t ldx, int32_t rows, int32_t c,
   if (rows <= 0 || c <= 0 || (c & 7) || (ldx & 7) || (ldy & 7)) TT_FAIL(TT_EINVAL, "tt_layernorm: c and strides must be multiples of 8");
   if (rowvec && (!xsum_out || rows_per_vec <= 0 || nvec <= 0)) TT_FAIL(TT_EINVAL, "tt_layernorm: rowvec needs xsum_out, rows_per_vec, nvec");
   if (c > 64 * 8 * 4) TT_FAIL(TT_EUNSUPPORTED, "tt_layernorm: c=%d > 2048", c);
-  if (dtype != TT_BF16 && dtype != TT_F16) TT_FAIL(TT_EINVAL, "tt_layernorm: bad dtype");
+  if (dtype != TT_BF16 && dtype != TT_F16 && dtype != TT_F32) TT_FAIL(TT_EINVAL, "tt_layernorm: bad dtype");
   hipStream_t st = (hipStream_t)stream;
   const dim3 grid((rows + 3) / 4), block(256);
 #define TT_LN(TAG, MV) hipLaunchKernelGGL((ln_kernel<TAG, MV>), grid, block, 0, st, (const char*)x, (long)ldx, rows, c, gamma, beta, eps, rowvec, rows_per_vec, nvec, (char*)xsum_out, (char*)y, (long)ldy)
   const int mv = (c / 8 + 63) / 64;
   if (dtype == TT_BF16) { if (mv <= 1) TT_LN(bf16_tag, 1); else if (mv <= 2) TT_LN(bf16_tag, 2); else TT_LN(bf16_tag, 4); }
-  else { if (mv <= 1) TT_LN(f16_tag, 1); else if (mv <= 2) TT_LN(f16_tag, 2); else TT_LN(f16_tag, 4); }
+  else if (dtype == TT_F16) { if (mv <= 1) TT_LN(f16_tag, 1); else if (mv <= 2) TT_LN(f16_tag, 2); else TT_LN(f16_tag, 4); }
+  else { if (mv <= 1) TT_LN(f32_tag, 1); else if (mv <= 2) TT_LN(f32_tag, 2); else TT_LN(f32_tag, 4); }
 #undef TT_LN
   TT_CHECK_LAUNCH("tt_layernorm");
   return TT_OK;

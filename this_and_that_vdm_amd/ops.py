@@ -9,7 +9,7 @@ from typing import Optional, Tuple
 import torch
 
 from . import _lib
-from ._lib import TT_BF16, TT_F16, TtAttnArgs, TtGemmArgs, check
+from ._lib import TT_BF16, TT_F16, TT_F32, TtAttnArgs, TtGemmArgs, check
 
 
 # Optional launch profiler (bench.py): when set to a list, gemm()/attention() append
@@ -55,7 +55,12 @@ def _code(dt: torch.dtype) -> int:
         return TT_BF16
     if dt == torch.float16:
         return TT_F16
-    raise RuntimeError(f"libttvdm activations/weights must be bfloat16 or float16, got {dt}")
+    if dt == torch.float32:
+        return TT_F32          # reference-precision mode (exact-fp32 MFMA): parity runs, not the benchmarked path
+    raise RuntimeError(f"libttvdm activations/weights must be bfloat16, float16 or float32, got {dt}")
+
+
+_TAG = {TT_BF16: "bf16_tag", TT_F16: "f16_tag", TT_F32: "f32_tag"}
 
 
 def _stream():
@@ -127,7 +132,7 @@ def gemm(a0: torch.Tensor, w: torch.Tensor, *, a1: Optional[torch.Tensor] = None
         cfg = (C.c_int32 * 7)()
         lib.tt_gemm_plan(C.byref(g), cfg)
         taps = 9 if mode == 1 else (3 if mode == 2 else 1)
-        tag = "bf16_tag" if g.dtype == TT_BF16 else "f16_tag"
+        tag = _TAG[g.dtype]
         if cfg[0] == 32 and cfg[1] == 320:          # the opt-in streaming kernel for the 320 x 320 linears
             kname = f"sq320_kernel<{tag}, {'true' if residual is not None else 'false'}>"
         else:
@@ -151,7 +156,7 @@ def attention(q, k, vt, out, *, nseq, lq, heads, head_dim, mask, lk, k_seq_strid
     ev = _prof_begin()
     check(lib.tt_attention(C.byref(a), _stream()), "tt_attention")
     if ev is not None:
-        tag = "bf16_tag" if a.dtype == TT_BF16 else "f16_tag"
+        tag = _TAG[a.dtype]
         keys = lk * (ctx_batches if mask == 2 else 1)
         _prof_end(ev, f"attn_kernel<{tag}, {head_dim}, {mask}>", 4.0 * nseq * heads * lq * lk * head_dim,
                   shape=("attn", nseq * heads, lq, lk, mask, 0))
@@ -266,7 +271,8 @@ def nchw_to_tokens(src, dtype, ld=None, out=None):
 def tokens_to_nchw(src, n, c, h, w, out_dtype):
     lib = _lib.load()
     src_f32 = src.dtype == torch.float32
-    tok_dtype = out_dtype if src_f32 and out_dtype != torch.float32 else (src.dtype if not src_f32 else torch.bfloat16)
+    # `dtype` names the 16-bit side of the conversion; fp32 -> fp32 (eps of the UNet, TT_F32 tokens) has none and passes TT_F32
+    tok_dtype = out_dtype if src_f32 and out_dtype != torch.float32 else (src.dtype if not src_f32 else torch.float32)
     dst_f32 = out_dtype == torch.float32
     if not dst_f32 and not src_f32:
         assert out_dtype == src.dtype

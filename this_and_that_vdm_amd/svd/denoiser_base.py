@@ -27,7 +27,9 @@ def as_nchw_view(tok: torch.Tensor, g: Geom) -> torch.Tensor:
 
 
 class DenoiserBase(ModelMixin):
-    compute_dtype: Optional[torch.dtype] = None      # None: parameter dtype if 16-bit, else bf16
+    # None: the parameter dtype if it is 16-bit, else bf16.  torch.float32 selects the reference-precision mode (TT_F32:
+    # the same launch sequence on fp32 storage with the exact-fp32 MFMA, ~1/16 of the bf16 rate) used by the parity tests.
+    compute_dtype: Optional[torch.dtype] = None
 
     # ---- packing
     _pack_gen = 0          # bumped by every (re)pack: consumers holding raw pointers to packed buffers (captured
