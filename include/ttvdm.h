@@ -56,6 +56,7 @@ const char* tt_last_error(void);
  * W is [n, taps*(k0+k1)] row-major with k index (tap, source, channel); two sources implement
  * torch.cat([h, skip], dim=1) (unet_3d_blocks.py:2242,2352) without a concat buffer.
  * Epilogue, in this order (every term optional):
+ *   acc *= 1/sigma of the LayerNorm-folded operand row (ln_fold, below)
  *   v = (acc + bias[n]) * acc_scale + rowvec[m / rowvec_rows][n]
  *   geglu: v = v_value * gelu_erf(v_gate)      (W rows pre-interleaved in 16-row groups: 8 value, 8 gate)
  *   v += residual[m][n];  v = alpha*blend[m][n] + (1-alpha)*v   (AlphaBlender, video branch)
@@ -79,6 +80,15 @@ typedef struct TtGemmArgs {
   int32_t out_col_hw, out_col_hwp;     /* if hw>0: column c -> (c/hw)*hwp + c%hw (padded V^T sequences) */
   int32_t dtype;
   void* ws; int64_t ws_bytes;          /* optional caller-owned scratch for split-K (tt_gemm_ws_bytes); NULL = never split */
+  /* Fused LayerNorm of one operand (nn.LayerNorm sites inside Basic/TemporalBasicTransformerBlock, reached from
+   * transformer_temporal.py:342-365; mode 0, k1 == 0, k0 = the LayerNorm width):
+   *   ln_fold 1   acc[m][n] is multiplied by 1/sqrt(var(a0 row m) + ln_eps)      -> out = LN(A) W^T
+   *   ln_fold 2   acc[m][n] is multiplied by 1/sqrt(var(w  row n) + ln_eps)      -> out = A LN(W)^T  (swapped V^T projection)
+   * before bias / acc_scale / the other epilogue terms.  The statistics are taken inside the K loop from the operand
+   * fragments themselves (no separate pass).  The CALLER folds the affine part: the un-normalised operand is multiplied by
+   * (weight * gamma), centred over k so that each weight row sums to zero (then x W^T == (x - mean) W^T), and beta
+   * enters through `bias` (this_and_that_vdm_amd/packing.py:fold_layernorm). */
+  int32_t ln_fold; float ln_eps;
 } TtGemmArgs;
 int tt_gemm(const TtGemmArgs* args, tt_stream_t stream);
 /* which tile configuration tt_gemm will use for this problem: cfg[0..6] = BM, BN, BK, ring stages, waves along M,
@@ -195,6 +205,11 @@ int tt_tokens_to_nchw(const void* src, int32_t src_f32, int64_t ld_src, int32_t 
                       int32_t dst_f32, int32_t dtype, tt_stream_t stream);
 /* y = a + b*scale (dtype, elementwise, n multiple of 8): ControlNet residual add, unet...:485-491,501-502. */
 int tt_add_scaled(const void* a, const void* b, float scale, void* y, int64_t n, int32_t dtype, tt_stream_t stream);
+/* y[r][c] = x[r][c] + rowvec[(r / rows_per_vec) % nvec][c]: the frame-position embedding added to the hidden states before
+ * the temporal transformer block (transformer_temporal.py:358-359; the block's norm_in is folded into its first GEMM).
+ * x, y `dtype` [rows, c] (c multiple of 8), rowvec fp32 [nvec, c]. */
+int tt_add_rowvec(const void* x, int64_t ldx, int32_t rows, int32_t c, const float* rowvec, int64_t ld_rowvec,
+                  int32_t rows_per_vec, int32_t nvec, void* y, int64_t ldy, int32_t dtype, tt_stream_t stream);
 
 #ifdef __cplusplus
 }

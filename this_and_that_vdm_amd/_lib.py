@@ -27,6 +27,7 @@ class TtGemmArgs(C.Structure):
         ("out", C.c_void_p), ("ldo", C.c_int64), ("out_f32", C.c_int32),
         ("out_col_hw", C.c_int32), ("out_col_hwp", C.c_int32), ("dtype", C.c_int32),
         ("ws", C.c_void_p), ("ws_bytes", C.c_int64),
+        ("ln_fold", C.c_int32), ("ln_eps", C.c_float),
     ]
 
 
@@ -66,6 +67,7 @@ SIGNATURES = {
     "tt_nchw_to_tokens": (C.c_int, [_vp, _i32, _i32, _i32, _i32, _vp, _i64, _i32, _vp]),
     "tt_tokens_to_nchw": (C.c_int, [_vp, _i32, _i64, _i32, _i32, _i32, _vp, _i32, _i32, _vp]),
     "tt_add_scaled": (C.c_int, [_vp, _vp, _f32, _vp, _i64, _i32, _vp]),
+    "tt_add_rowvec": (C.c_int, [_vp, _i64, _i32, _i32, _vp, _i64, _i32, _i32, _vp, _i64, _i32, _vp]),
 }
 
 _lib = None
@@ -92,7 +94,7 @@ def load():
     for name, (res, args) in SIGNATURES.items():
         fn = getattr(lib, name)          # AttributeError here == ABI mismatch with include/ttvdm.h
         fn.restype, fn.argtypes = res, args
-    if lib.tt_abi_version() != 1:
+    if lib.tt_abi_version() != 2:
         raise RuntimeError("libttvdm.so ABI version mismatch")
     _lib = lib
     return lib

@@ -179,7 +179,39 @@ __global__ void add_scaled_kernel(const char* a, const char* b, float scale, cha
   }
 }
 
+template <typename Tag>
+__global__ void add_rowvec_kernel(const char* x, long ldx, int rows, int cv, const float* rv, long ld_rv, int rows_per_vec,
+                                  int nvec, char* y, long ldy) {
+  const long total = (long)rows * cv;
+  for (long v = (long)blockIdx.x * blockDim.x + threadIdx.x; v < total; v += (long)gridDim.x * blockDim.x) {
+    const long row = v / cv;
+    const int ch = (int)(v - row * cv) * 8;
+    const float* r = rv + (long)((row / rows_per_vec) % nvec) * ld_rv + ch;
+    float f[8];
+    load8<Tag>(x + (row * ldx + ch) * Elem<Tag>::ES, f);
+    const float4 a = *(const float4*)r, b = *(const float4*)(r + 4);
+    f[0] += a.x; f[1] += a.y; f[2] += a.z; f[3] += a.w; f[4] += b.x; f[5] += b.y; f[6] += b.z; f[7] += b.w;
+    store8<Tag>(y + (row * ldy + ch) * Elem<Tag>::ES, f);
+  }
+}
+
 }  // namespace
+
+extern "C" int tt_add_rowvec(const void* x, int64_t ldx, int32_t rows, int32_t c, const float* rowvec, int64_t ld_rowvec,
+                             int32_t rows_per_vec, int32_t nvec, void* y, int64_t ldy, int32_t dtype, tt_stream_t stream) {
+  if (!x || !rowvec || !y) TT_FAIL(TT_EINVAL, "tt_add_rowvec: null operand");
+  if (rows <= 0 || c <= 0 || (c & 7) || (ldx & 7) || (ldy & 7) || (ld_rowvec & 3) || rows_per_vec <= 0 || nvec <= 0)
+    TT_FAIL(TT_EINVAL, "tt_add_rowvec: c and strides must be multiples of 8 (rowvec stride of 4), rows_per_vec / nvec positive");
+  if (dtype != TT_BF16 && dtype != TT_F16 && dtype != TT_F32) TT_FAIL(TT_EINVAL, "tt_add_rowvec: bad dtype");
+  const long total = (long)rows * (c >> 3);
+  long blocks = (total + 255) / 256; if (blocks > 4096) blocks = 4096;
+  hipStream_t st = (hipStream_t)stream;
+#define TT_ARV(TAG) hipLaunchKernelGGL(add_rowvec_kernel<TAG>, dim3((unsigned)blocks), dim3(256), 0, st, (const char*)x, (long)ldx, rows, c >> 3, rowvec, (long)ld_rowvec, rows_per_vec, nvec, (char*)y, (long)ldy)
+  if (dtype == TT_BF16) TT_ARV(bf16_tag); else if (dtype == TT_F16) TT_ARV(f16_tag); else TT_ARV(f32_tag);
+#undef TT_ARV
+  TT_CHECK_LAUNCH("tt_add_rowvec");
+  return TT_OK;
+}
 
 extern "C" int tt_small_linear(const float* x, int64_t ldx, int32_t rows, int32_t k, const void* w, int64_t ldw, int32_t n,
                                const float* bias, int32_t act_in, int32_t act_out, int32_t accumulate, float* y, int64_t ldy,

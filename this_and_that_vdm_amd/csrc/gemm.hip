@@ -128,15 +128,24 @@ extern "C" int tt_gemm_set_streaming_square(int32_t on) {
 
 bool sq320_ok(const TtGemmArgs* a) {
   if (g_sq320 < 0) { const char* e = getenv("TT_GEMM_SQ320"); g_sq320 = e ? atoi(e) : 0; }
-  return g_sq320 && a->dtype != TT_F32 && forced_cfg() < 0 && a->mode == 0 && a->k1 == 0 && a->k0 == SQ_K && a->n == SQ_N && a->m >= 4096 &&
+  return g_sq320 && a->dtype != TT_F32 && !a->ln_fold && forced_cfg() < 0 && a->mode == 0 && a->k1 == 0 && a->k0 == SQ_K && a->n == SQ_N && a->m >= 4096 &&
          !a->geglu && !a->rowvec && !a->out_f32 && !a->out_col_hw &&
          (!a->blend || (a->blend == a->residual && a->ld_blend == a->ld_res));
 }
+// tile shapes whose fused-LayerNorm variants are built (launch<Tag>() in gemm_kernel.h): the ones the planner picks
+static bool ln_capable(int cfg) { return cfg == 1 || cfg == 2 || cfg == 3 || cfg == 7 || cfg == 11 || cfg == 16; }
 static Plan plan_for(const TtGemmArgs* a) {
   if (a->dtype == TT_F32) return Plan{plan_f32(a->m, a->n), 1};
   const int taps = a->mode == 1 ? 9 : (a->mode == 2 ? 3 : 1);
-  const bool allow = !a->geglu;
-  return make_plan(a->m, a->n, (long)taps * (a->k0 + a->k1), allow, !(a->residual || a->blend || a->rowvec));
+  const bool allow = !a->geglu && !a->ln_fold;       // a K slice would see only part of a LayerNorm row
+  Plan pl = make_plan(a->m, a->n, (long)taps * (a->k0 + a->k1), allow, !(a->residual || a->blend || a->rowvec));
+  if (a->ln_fold && !ln_capable(pl.cfg)) {           // a forced tile shape without the fused variant: planner's own choice
+    const int keep = g_forced_cfg;
+    g_forced_cfg = -1;
+    pl = make_plan(a->m, a->n, (long)taps * (a->k0 + a->k1), false, !(a->residual || a->blend || a->rowvec));
+    g_forced_cfg = keep;
+  }
+  return pl;
 }
 
 extern "C" int tt_gemm_plan(const TtGemmArgs* a, int32_t cfg[7]) {
@@ -171,6 +180,10 @@ extern "C" int tt_gemm(const TtGemmArgs* a, tt_stream_t stream) {
   if (a->geglu && ((a->n & 15) || a->residual || a->blend || a->rowvec || a->out_f32 || a->out_col_hw))
     TT_FAIL(TT_EINVAL, "tt_gemm: geglu needs n %% 16 == 0 and no other epilogue terms");
   if (a->rowvec && a->rowvec_rows <= 0) TT_FAIL(TT_EINVAL, "tt_gemm: rowvec_rows");
+  if (a->ln_fold < 0 || a->ln_fold > 2) TT_FAIL(TT_EINVAL, "tt_gemm: ln_fold %d (0 none, 1 rows of A, 2 rows of W)", a->ln_fold);
+  if (a->ln_fold && (a->mode != 0 || a->k1 != 0 || !(a->ln_eps > 0.f)))
+    TT_FAIL(TT_EINVAL, "tt_gemm: ln_fold needs mode 0, one source spanning the whole LayerNorm row (k0 = C) and ln_eps > 0");
+  if (a->ln_fold == 2 && a->geglu) TT_FAIL(TT_EINVAL, "tt_gemm: ln_fold 2 (columns) cannot be combined with geglu");
   GemmP p;
   p.a0 = (const char*)a->a0; p.a1 = (const char*)a->a1; p.k0 = a->k0; p.k1 = a->k1;
   p.lda0 = a->lda0; p.lda1 = a->lda1; p.w = (const char*)a->w; p.ldw = a->ldw;
@@ -184,6 +197,7 @@ extern "C" int tt_gemm(const TtGemmArgs* a, tt_stream_t stream) {
   const int es = a->dtype == TT_F32 ? 4 : 2;         // bytes per stored element
   p.out = (char*)a->out; p.ldo = a->ldo; p.out_f32 = a->dtype == TT_F32 ? 0 : a->out_f32;   // TT_F32 stores fp32 anyway
   p.out_col_hw = a->out_col_hw; p.out_col_hwp = a->out_col_hwp;
+  p.ln_fold = a->ln_fold; p.ln_eps = a->ln_eps;
   if (p.mode == 1) {
     if (p.nimg <= 0 || p.hin <= 0 || p.win <= 0 || p.hout <= 0 || p.wout <= 0 || p.stride < 1)
       TT_FAIL(TT_EINVAL, "tt_gemm: conv geometry");

@@ -28,7 +28,36 @@ struct GemmP {
   unsigned out_bytes, res_bytes, blend_bytes, bias_bytes, rowvec_bytes, ws_bytes;   // epilogue descriptors (0 = absent)
   int splitk;                       // > 1: block (tile, s) reduces K slice s and writes an fp32 slab to ws
   float* ws;                        // [splitk][m][n] fp32 partial sums
+  int ln_fold; float ln_eps;        // fused LayerNorm of the A rows (1) / W rows (2): see gemm_kernel, MODE 3 / 4
 };
+
+// ---- running sum and sum of squares of one 16-byte MFMA operand chunk (fused LayerNorm statistics).  16-bit storage: two
+// packed dot products per dword (v_dot2_f32_*: x . (1,1) and x . x, accumulated in fp32) -- the operand stays packed.
+typedef __attribute__((ext_vector_type(2))) _Float16 ln_half2;
+typedef __attribute__((ext_vector_type(2))) __bf16 ln_bf162;
+template <typename Tag> __device__ __forceinline__ void ln_stat(const raw_u32x4_t& f, float& s, float& q);
+template <> __device__ __forceinline__ void ln_stat<bf16_tag>(const raw_u32x4_t& f, float& s, float& q) {
+  const ln_bf162 one = __builtin_bit_cast(ln_bf162, 0x3F803F80u);
+#pragma unroll
+  for (int d = 0; d < 4; ++d) {
+    const ln_bf162 x = __builtin_bit_cast(ln_bf162, f[d]);
+    s = __builtin_amdgcn_fdot2_f32_bf16(x, one, s, false);
+    q = __builtin_amdgcn_fdot2_f32_bf16(x, x, q, false);
+  }
+}
+template <> __device__ __forceinline__ void ln_stat<f16_tag>(const raw_u32x4_t& f, float& s, float& q) {
+  const ln_half2 one = __builtin_bit_cast(ln_half2, 0x3C003C00u);
+#pragma unroll
+  for (int d = 0; d < 4; ++d) {
+    const ln_half2 x = __builtin_bit_cast(ln_half2, f[d]);
+    s = __builtin_amdgcn_fdot2(x, one, s, false);
+    q = __builtin_amdgcn_fdot2(x, x, q, false);
+  }
+}
+template <> __device__ __forceinline__ void ln_stat<f32_tag>(const raw_u32x4_t& f, float& s, float& q) {
+#pragma unroll
+  for (int d = 0; d < 4; ++d) { const float x = __uint_as_float(f[d]); s += x; q = fmaf(x, x, q); }
+}
 
 
 // ---- optional per-block timeline (make timeline): thread 0 of every block stamps the 100 MHz wall clock
@@ -145,10 +174,18 @@ constexpr int gemm_min_waves(int BM, int BN, int CPR, int NST, int NT) {
   return w < 1 ? 1 : w;
 }
 
-template <typename Tag, int BM, int BN, int BK, int NST, int WGM, int WGN, int MODE>
+// KMODE: 0 Linear, 1 conv3x3, 2 temporal conv, and two Linear variants with a fused LayerNorm (transformer blocks):
+//   3  out = LN(A rows) W^T        4  out = A LN(W rows)^T   (the swapped V^T projection: the tokens are the "W" operand)
+// The caller folds gamma into the weights, centres them over k (rows sum to zero, so the mean of x drops out of x W^T) and
+// folds beta into the bias; what remains is the per-token 1/sigma.  Every lane sees ALL K values of "its" operand row pass
+// through its registers as MFMA fragments (row l31, chunk parity hi), so sum and sum of squares cost two packed dot
+// products per dword next to the MFMAs -- no statistics pass, no extra memory traffic, no normalised copy of the tensor.
+template <typename Tag, int BM, int BN, int BK, int NST, int WGM, int WGN, int KMODE>
 __global__ __launch_bounds__(64 * WGM * WGN, gemm_min_waves(BM, BN, BK / Elem<Tag>::EPC, NST, 64 * WGM * WGN))
 void gemm_kernel(const GemmP p) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
+  constexpr int MODE = KMODE >= 3 ? 0 : KMODE;         // gather mode
+  constexpr int LN = KMODE >= 3 ? KMODE - 2 : 0;       // 0 none, 1 statistics of A rows, 2 of W rows
   TL(0);
   typedef typename Elem<Tag>::quad_t quad_t;
   constexpr int ES = Elem<Tag>::ES, EPC = Elem<Tag>::EPC;   // bytes per element, elements per 16-byte chunk
@@ -333,7 +370,18 @@ void gemm_kernel(const GemmP p) {
 #pragma unroll
     for (int j = 0; j < FN; ++j) bf[j] = lds_read16_raw(sb + tile_off<CPR>(b_lds_row[j], chunk));
   };
+  constexpr int NLN = LN == 1 ? FM : (LN == 2 ? FN : 1);
+  float ln_s[NLN], ln_q[NLN];
+#pragma unroll
+  for (int i = 0; i < NLN; ++i) ln_s[i] = ln_q[i] = 0.f;
   auto mma = [&](const raw_u32x4_t (&af)[FM], const raw_u32x4_t (&bf)[FN]) {
+    if constexpr (LN == 1) {
+#pragma unroll
+      for (int i = 0; i < FM; ++i) ln_stat<Tag>(af[i], ln_s[i], ln_q[i]);
+    } else if constexpr (LN == 2) {
+#pragma unroll
+      for (int j = 0; j < FN; ++j) ln_stat<Tag>(bf[j], ln_s[j], ln_q[j]);
+    }
 #pragma unroll
     for (int i = 0; i < FM; ++i)
 #pragma unroll
@@ -443,6 +491,34 @@ void gemm_kernel(const GemmP p) {
     }
   }
 
+  // ---- fused LayerNorm: 1/sigma of the operand rows from the sums gathered beside the MFMAs (the two lane halves hold the
+  // even / odd chunks of a row).  Rows: scale the accumulators now (lane <-> row l31).  Columns: the lane that owns W row
+  // l31 of fragment j publishes 1/sigma of output column j*32 + l31 in a wave-private LDS array behind the ring; the
+  // epilogue multiplies by it where a lane holds four consecutive columns.
+  constexpr int CS_OFF = NST * STAGE;                  // MODE 4 only: WGM*WGN KiB more dynamic LDS (launch_mode)
+  if constexpr (LN != 0) {
+    const float inv_k = 1.0f / (float)p.k0;
+    float rs[NLN];
+#pragma unroll
+    for (int i = 0; i < NLN; ++i) {
+      const float sm = (ln_s[i] + __shfl_xor(ln_s[i], 32)) * inv_k, sq = (ln_q[i] + __shfl_xor(ln_q[i], 32)) * inv_k;
+      rs[i] = rsqrtf(fmaxf(sq - sm * sm, 0.f) + p.ln_eps);
+    }
+    if constexpr (LN == 1) {
+#pragma unroll
+      for (int i = 0; i < FM; ++i)
+#pragma unroll
+        for (int j = 0; j < FN; ++j)
+#pragma unroll
+          for (int r = 0; r < 16; ++r) acc[i][j][r] *= rs[i];
+    } else {
+      float* cs = (float*)(smem + CS_OFF + wid * 1024);
+#pragma unroll
+      for (int j = 0; j < FN; ++j) cs[j * 32 + l31] = rs[j];          // both lane halves write the same value
+    }
+  }
+  const float* colscale = (const float*)(smem + CS_OFF + wid * 1024);   // read only when LN == 2
+
   // ---- epilogue.  The MFMA layout gives a lane row m = .. + l31 and columns n = .. + 8g + 4hi + {0..3}: stored
   // directly, one instruction would touch 32 rows x 16 bytes.  Instead each wave transposes its accumulators through a
   // private LDS strip (fp32, 32 rows x 64 columns at a time) and re-reads them so that 16 consecutive lanes cover 64
@@ -496,6 +572,8 @@ void gemm_kernel(const GemmP p) {
             const int qq = lane % q_per_row, rr = lane / q_per_row;
             const int gn = n0 + wc * WTN + jc * 32 + qq * 4;
             const float4 b4 = bias4[jc / 2];
+            float4 cs4 = make_float4(1.f, 1.f, 1.f, 1.f);
+            if constexpr (LN == 2) cs4 = *(const float4*)(colscale + jc * 32 + qq * 4);
             float4 film_lo = make_float4(0.f, 0.f, 0.f, 0.f), film_hi = film_lo;
             if constexpr (FILM) {
               film_lo = ld128f(r_rv, (mb < p.m && gn < p.n) ? (int)(((long)grp0 * p.ld_rowvec + gn) * 4) : kInv);
@@ -542,8 +620,8 @@ void gemm_kernel(const GemmP p) {
                   if (p.splitk > 1) {                    // uniform: fp32 partial sums of K slice `split`
                     st128f(r_out, ok ? (int)((((long)split * p.m + gm) * p.n + gn) * 4) : kInv, t);
                   } else {
-                    float v[4] = {(t.x + b4.x) * p.acc_scale, (t.y + b4.y) * p.acc_scale, (t.z + b4.z) * p.acc_scale,
-                                  (t.w + b4.w) * p.acc_scale};
+                    float v[4] = {(t.x * cs4.x + b4.x) * p.acc_scale, (t.y * cs4.y + b4.y) * p.acc_scale,
+                                  (t.z * cs4.z + b4.z) * p.acc_scale, (t.w * cs4.w + b4.w) * p.acc_scale};
                     const quad_t rq = rqv[k];
                     quad_t bq = rq;
                     if constexpr (FILM) {
@@ -644,6 +722,10 @@ void gemm_kernel(const GemmP p) {
         float v[4];
 #pragma unroll
         for (int e = 0; e < 4; ++e) v[e] = acc[i][j][g * 4 + e];
+        if constexpr (LN == 2) {
+          const float4 c4 = *(const float4*)(colscale + j * 32 + 8 * g + 4 * hi);
+          v[0] *= c4.x; v[1] *= c4.y; v[2] *= c4.z; v[3] *= c4.w;
+        }
         epilogue_quad<Tag>(p, gm, gn, v);
       }
     }
@@ -832,8 +914,10 @@ __global__ __launch_bounds__(256) void splitk_epilogue_kernel(const GemmP p) {
 template <typename Tag, int BM, int BN, int BK, int NST, int WGM, int WGN, int MODE>
 void launch_mode(const GemmP& p, hipStream_t st) {
   constexpr int NT_ = 64 * WGM * WGN, CPR_ = BK / Elem<Tag>::EPC;
-  constexpr size_t lds = (size_t)NST * (((BM * CPR_ + NT_ - 1) / NT_) + ((BN * CPR_ + NT_ - 1) / NT_)) * NT_ * 16;
+  constexpr size_t lds = (size_t)NST * (((BM * CPR_ + NT_ - 1) / NT_) + ((BN * CPR_ + NT_ - 1) / NT_)) * NT_ * 16
+                         + (MODE == 4 ? WGM * WGN * 1024 : 0);          // + the per-wave column-scale arrays
   static_assert(lds <= 160 * 1024, "LDS ring exceeds 160 KiB");
+  static_assert(MODE != 4 || BN / WGN <= 256, "column-scale array: 1 KiB per wave");
   static unsigned long long attr_done = 0;     // per kernel instance, one bit per device (see tt_lds_opt_in)
   tt_lds_opt_in((const void*)gemm_kernel<Tag, BM, BN, BK, NST, WGM, WGN, MODE>, (int)lds, &attr_done);
   hipLaunchKernelGGL((gemm_kernel<Tag, BM, BN, BK, NST, WGM, WGN, MODE>), dim3(p.tiles_m * p.tiles_n * p.splitk),
@@ -845,12 +929,18 @@ void launch_mode(const GemmP& p, hipStream_t st) {
   }
 }
 
-template <typename Tag, int BM, int BN, int BK, int NST, int WGM, int WGN>
+// LNOK: also instantiate the fused-LayerNorm variants (only the tile shapes the planner picks; gemm.hip keeps LayerNorm
+// problems on them)
+template <typename Tag, int BM, int BN, int BK, int NST, int WGM, int WGN, bool LNOK = false>
 void launch_cfg(GemmP& p, hipStream_t st) {
   p.tiles_m = ceil_div(p.m, BM);
   p.tiles_n = ceil_div(p.n, BN);
   p.nk0 = ceil_div(p.k0, BK); p.nk1 = p.k1 ? ceil_div(p.k1, BK) : 0;
   p.kt_total = p.taps * (p.nk0 + p.nk1);
+  if constexpr (LNOK) {
+    if (p.ln_fold == 1) { launch_mode<Tag, BM, BN, BK, NST, WGM, WGN, 3>(p, st); return; }
+    if (p.ln_fold == 2) { launch_mode<Tag, BM, BN, BK, NST, WGM, WGN, 4>(p, st); return; }
+  }
   switch (p.mode) {
     case 0: launch_mode<Tag, BM, BN, BK, NST, WGM, WGN, 0>(p, st); break;
     case 1: launch_mode<Tag, BM, BN, BK, NST, WGM, WGN, 1>(p, st); break;
@@ -872,22 +962,22 @@ template <typename Tag>
 void launch(GemmP& p, int cfg, hipStream_t st) {          // cfg = index into kCfgs (gemm.hip)
   switch (cfg) {
     case 0: launch_cfg<Tag, 128, 128, 64, 2, 2, 2>(p, st); break;
-    case 1: launch_cfg<Tag, 128, 64, 64, 3, 2, 2>(p, st); break;
-    case 2: launch_cfg<Tag, 64, 64, 64, 4, 2, 2>(p, st); break;
-    case 3: launch_cfg<Tag, 256, 128, 32, 3, 4, 2>(p, st); break;
+    case 1: launch_cfg<Tag, 128, 64, 64, 3, 2, 2, true>(p, st); break;
+    case 2: launch_cfg<Tag, 64, 64, 64, 4, 2, 2, true>(p, st); break;
+    case 3: launch_cfg<Tag, 256, 128, 32, 3, 4, 2, true>(p, st); break;
     case 4: launch_cfg<Tag, 256, 256, 32, 3, 2, 4>(p, st); break;
     case 5: launch_cfg<Tag, 128, 128, 32, 3, 2, 2>(p, st); break;
     case 6: launch_cfg<Tag, 256, 128, 64, 3, 4, 2>(p, st); break;
-    case 7: launch_cfg<Tag, 128, 160, 64, 2, 4, 1>(p, st); break;
+    case 7: launch_cfg<Tag, 128, 160, 64, 2, 4, 1, true>(p, st); break;
     case 8: launch_cfg<Tag, 128, 320, 32, 3, 4, 2>(p, st); break;
     case 9: launch_cfg<Tag, 256, 256, 64, 2, 2, 4>(p, st); break;
     case 10: launch_cfg<Tag, 128, 128, 64, 4, 2, 2>(p, st); break;
-    case 11: launch_cfg<Tag, 128, 128, 64, 2, 4, 2>(p, st); break;
+    case 11: launch_cfg<Tag, 128, 128, 64, 2, 4, 2, true>(p, st); break;
     case 12: launch_cfg<Tag, 256, 160, 32, 3, 8, 1>(p, st); break;
     case 13: launch_cfg<Tag, 256, 128, 32, 4, 4, 2>(p, st); break;
     case 14: launch_cfg<Tag, 128, 128, 32, 5, 4, 2>(p, st); break;
     case 15: launch_cfg<Tag, 128, 128, 64, 3, 4, 2>(p, st); break;
-    default: launch_cfg<Tag, 128, 128, 64, 4, 4, 2>(p, st); break;
+    default: launch_cfg<Tag, 128, 128, 64, 4, 4, 2, true>(p, st); break;
   }
 }
 
@@ -895,8 +985,8 @@ void launch(GemmP& p, int cfg, hipStream_t st) {          // cfg = index into kC
 // elements give the 128-byte tile rows of the 16-bit BK = 64 configurations; no split-K (one summation order).
 template <>
 inline void launch<f32_tag>(GemmP& p, int cfg, hipStream_t st) {
-  if (cfg == 0) launch_cfg<f32_tag, 128, 128, 32, 2, 2, 2>(p, st);
-  else launch_cfg<f32_tag, 64, 64, 32, 4, 2, 2>(p, st);
+  if (cfg == 0) launch_cfg<f32_tag, 128, 128, 32, 2, 2, 2, true>(p, st);
+  else launch_cfg<f32_tag, 64, 64, 32, 4, 2, 2, true>(p, st);
 }
 
 }  // namespace ttg

@@ -84,9 +84,10 @@ def _rows2d(t: torch.Tensor) -> Tuple[int, int]:
 def gemm(a0: torch.Tensor, w: torch.Tensor, *, a1: Optional[torch.Tensor] = None, mode: int = 0, conv=None, tconv=None,
          bias=None, acc_scale: float = 1.0, rowvec=None, rowvec_rows: int = 0, geglu: bool = False, residual=None,
          blend=None, alpha: float = 0.0, out: Optional[torch.Tensor] = None, out_f32: bool = False, m: Optional[int] = None,
-         out_col_pad: Optional[Tuple[int, int]] = None) -> torch.Tensor:
+         out_col_pad: Optional[Tuple[int, int]] = None, ln_fold: int = 0, ln_eps: float = 1e-5) -> torch.Tensor:
     """out[m, n] = epilogue(gather(a0|a1) @ w.T); see TtGemmArgs in include/ttvdm.h.
-    conv = (nimg, hin, win, hout, wout, stride, upsample); tconv = (frames, hw)."""
+    conv = (nimg, hin, win, hout, wout, stride, upsample); tconv = (frames, hw).
+    ln_fold: 1 = rows of a0 / 2 = rows of w are LayerNorm inputs (weights pre-folded by packing.fold_layernorm)."""
     lib = _lib.load()
     g = TtGemmArgs()
     lda0, k0 = _rows2d(a0)
@@ -122,6 +123,7 @@ def gemm(a0: torch.Tensor, w: torch.Tensor, *, a1: Optional[torch.Tensor] = None
     if out_col_pad is not None:
         g.out_col_hw, g.out_col_hwp = out_col_pad
     g.dtype = _code(a0.dtype)
+    g.ln_fold, g.ln_eps = int(ln_fold), float(ln_eps)
     need = lib.tt_gemm_ws_bytes(C.byref(g))
     if need:
         ws = _workspace(need, a0.device)
@@ -136,7 +138,7 @@ def gemm(a0: torch.Tensor, w: torch.Tensor, *, a1: Optional[torch.Tensor] = None
         if cfg[0] == 32 and cfg[1] == 320:          # the opt-in streaming kernel for the 320 x 320 linears
             kname = f"sq320_kernel<{tag}, {'true' if residual is not None else 'false'}>"
         else:
-            kname = f"gemm_kernel<{tag}, {', '.join(str(v) for v in cfg[:6])}, {mode}>"
+            kname = f"gemm_kernel<{tag}, {', '.join(str(v) for v in cfg[:6])}, {mode if not ln_fold else 2 + ln_fold}>"
         _prof_end(ev, kname, 2.0 * g.m * n * taps * (g.k0 + g.k1),
                   shape=(mode, g.m, n, taps * (g.k0 + g.k1), int(geglu), int(residual is not None)))
     return out
@@ -207,6 +209,17 @@ def layernorm(x, gamma, beta, eps=1e-5, rowvec=None, rows_per_vec=0, nvec=0):
     check(lib.tt_layernorm(_p(x), x.stride(0), rows, c, _p(gamma), _p(beta), eps, _p(rowvec), rows_per_vec, nvec, _p(xs),
                            _p(y), y.stride(0), _code(x.dtype), _stream()), "tt_layernorm")
     return (xs, y) if xs is not None else y
+
+
+def add_rowvec(x, rowvec, rows_per_vec: int, nvec: int):
+    """y[r] = x[r] + rowvec[(r // rows_per_vec) % nvec]  (frame-position embedding, transformer_temporal.py:358-359)."""
+    lib = _lib.load()
+    rows, c = x.shape
+    assert x.stride(1) == 1 and rowvec.dtype == torch.float32 and rowvec.stride(1) == 1
+    y = torch.empty((rows, c), dtype=x.dtype, device=x.device)
+    check(lib.tt_add_rowvec(_p(x), x.stride(0), rows, c, _p(rowvec), rowvec.stride(0), rows_per_vec, nvec, _p(y), y.stride(0),
+                            _code(x.dtype), _stream()), "tt_add_rowvec")
+    return y
 
 
 def small_linear(x, w, bias=None, act_in=False, act_out=False, out=None, accumulate=False):

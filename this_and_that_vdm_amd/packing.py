@@ -39,3 +39,19 @@ def pad_rows(w: torch.Tensor, multiple: int) -> torch.Tensor:
     out = torch.zeros((np_,) + tuple(w.shape[1:]), dtype=w.dtype, device=w.device)
     out[:n] = w
     return out
+
+
+def fold_layernorm(weight: torch.Tensor, bias, gamma: torch.Tensor, beta: torch.Tensor):
+    """Fold the affine part of ``nn.LayerNorm`` (gamma, beta) into the ``nn.Linear`` that consumes it, for tt_gemm's
+    ``ln_fold`` (include/ttvdm.h):   Linear(LN(x)) = rstd * ((x - mean) (W*gamma)^T) + (W beta + bias).
+    Returns (W'', b') in fp32 with  W'' = W*gamma - rowmean_k(W*gamma):  rows that sum to zero make
+    x W''^T == (x - mean) W''^T for ANY x (the row mean of x multiplies sum_k W''[n,k] = 0), so the kernel can run on the
+    raw activations and only has to scale each output row by rstd, which it measures itself from the operand stream.
+    weight [N, K]; bias [N] or None; gamma, beta [K]."""
+    w = weight.detach().float()
+    wg = w * gamma.detach().float()[None, :]
+    wc = wg - wg.mean(dim=1, keepdim=True)
+    b = w @ beta.detach().float()
+    if bias is not None:
+        b = b + bias.detach().float()
+    return wc.contiguous(), b.contiguous()

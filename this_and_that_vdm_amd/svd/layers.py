@@ -18,7 +18,7 @@ import torch
 import torch.nn as nn
 
 from .. import ops
-from ..packing import pack_conv1x1, pack_conv3x3, pack_geglu, pack_tconv3
+from ..packing import fold_layernorm, pack_conv1x1, pack_conv3x3, pack_geglu, pack_tconv3
 
 
 @dataclass
@@ -320,30 +320,41 @@ class FeedForward(_Packable):
         inner = int(dim * mult)
         self.net = nn.ModuleList([GEGLU(dim, inner), nn.Dropout(dropout), nn.Linear(inner, dim_out if dim_out is not None else dim)])
 
-    def pack(self, reg, dtype):
-        self.wg, self.bg = pack_geglu(self.net[0].proj.weight.detach().to(dtype), _f32(self.net[0].proj.bias))
+    def pack(self, reg, dtype, norm: Optional[nn.LayerNorm] = None):
+        """``norm``: the LayerNorm in front of this feed-forward; it is folded into the GEGLU projection (tt_gemm ln_fold)."""
+        w, b = self.net[0].proj.weight.detach(), self.net[0].proj.bias
+        self.ln_fold, self.ln_eps = 0, 1e-5
+        if norm is not None:
+            w, b = fold_layernorm(w, b, norm.weight, norm.bias)
+            self.ln_fold, self.ln_eps = 1, norm.eps
+        self.wg, self.bg = pack_geglu(w.to(dtype), _f32(b))
         self.w2, self.b2 = self.net[2].weight.detach().to(dtype).contiguous(), _f32(self.net[2].bias)
 
     def forward(self, x, residual, blend=None, alpha=0.0):
-        hid = ops.gemm(x, self.wg, bias=self.bg, geglu=True)             # the 8C tensor never exists
+        """x: the UN-normalised hidden states when a LayerNorm was folded in at pack()."""
+        hid = ops.gemm(x, self.wg, bias=self.bg, geglu=True, ln_fold=self.ln_fold, ln_eps=self.ln_eps)   # the 8C tensor never exists
         return ops.gemm(hid, self.w2, bias=self.b2, residual=residual, blend=blend, alpha=alpha)
 
 
-def _self_attention(x_norm, attn: Attention, wqk, wv, g: Geom, ctx: StepContext):
-    """spatial self-attention over hw tokens per frame: QK projection, V^T projection (swapped GEMM), flash kernel."""
+def _self_attention(x, attn: Attention, wqk, bqk, wv, eps, g: Geom, ctx: StepContext):
+    """spatial self-attention over hw tokens per frame on the UN-normalised hidden states: norm1 is folded into the QK
+    projection (rows) and into the swapped V^T projection (columns); flash kernel."""
     c = attn.inner_dim
-    qk = ops.gemm(x_norm, wqk)                                            # [M, 2C]
+    qk = ops.gemm(x, wqk, bias=bqk, ln_fold=1, ln_eps=eps)                # [M, 2C]
     hwp = (g.hw + 7) // 8 * 8
-    vt = ctx.vt_buffer(c, g.n * hwp, x_norm)
-    ops.gemm(wv, x_norm, out=vt, out_col_pad=(g.hw, hwp) if hwp != g.hw else None)
+    vt = ctx.vt_buffer(c, g.n * hwp, x)
+    ops.gemm(wv, x, out=vt, out_col_pad=(g.hw, hwp) if hwp != g.hw else None, ln_fold=2, ln_eps=eps)
+    x_norm = x
     out = torch.empty((g.m, c), dtype=x_norm.dtype, device=x_norm.device)
     return ops.attention(qk[:, :c], qk[:, c:], vt, out, nseq=g.n, lq=g.hw, heads=attn.heads, head_dim=attn.dim_head,
                          mask=0, lk=g.hw, k_seq_stride=g.hw, v_seq_stride=hwp)
 
 
-def _cross_attention(x_norm, attn: Attention, wq, kv, g: Geom, ctx: StepContext, temporal: bool):
+def _cross_attention(x, attn: Attention, wq, bq, eps, kv, g: Geom, ctx: StepContext, temporal: bool):
+    """cross-attention on the UN-normalised hidden states (norm2 folded into the query projection)."""
     off, c = kv
-    q = ops.gemm(x_norm, wq)
+    q = ops.gemm(x, wq, bias=bq, ln_fold=1, ln_eps=eps)
+    x_norm = x
     out = torch.empty((g.m, c), dtype=x_norm.dtype, device=x_norm.device)
     return ops.attention(q, ctx.k_all[:, off:off + c], ctx.vt_all[off:off + c], out, nseq=g.n, lq=g.hw, heads=attn.heads,
                          head_dim=attn.dim_head, mask=2 if temporal else 1, lk=ctx.s_ctx, k_seq_stride=ctx.s_pad,
@@ -363,22 +374,31 @@ class BasicTransformerBlock(_Packable):
         self.ff = FeedForward(dim)
 
     def pack(self, reg, dtype):
+        """The three LayerNorms are folded into the GEMMs that consume them (packing.fold_layernorm, tt_gemm ln_fold): no
+        LayerNorm kernel and no normalised copy of the hidden states exist.  norm1's beta reaches V as the constant vector
+        Wv beta added to every key's value; softmax rows sum to 1, so it passes through attention unchanged and is added to
+        to_out's bias (Wo (Wv beta))."""
         cv = lambda t: t.detach().to(dtype).contiguous()
-        self.ln = [(_f32(n.weight), _f32(n.bias)) for n in (self.norm1, self.norm2, self.norm3)]
-        self.wqk = cv(torch.cat([self.attn1.to_q.weight, self.attn1.to_k.weight], 0))
-        self.wv = cv(self.attn1.to_v.weight)
-        self.wo1, self.bo1 = cv(self.attn1.to_out[0].weight), _f32(self.attn1.to_out[0].bias)
-        self.wq2 = cv(self.attn2.to_q.weight)
+        n1, n2 = self.norm1, self.norm2
+        wq, bq = fold_layernorm(self.attn1.to_q.weight, None, n1.weight, n1.bias)
+        wk, bk = fold_layernorm(self.attn1.to_k.weight, None, n1.weight, n1.bias)
+        wv, bv = fold_layernorm(self.attn1.to_v.weight, None, n1.weight, n1.bias)
+        self.wqk, self.bqk = cv(torch.cat([wq, wk], 0)), torch.cat([bq, bk], 0).contiguous()
+        self.wv = cv(wv)
+        self.wo1 = cv(self.attn1.to_out[0].weight)
+        self.bo1 = (_f32(self.attn1.to_out[0].bias) + self.wo1.float() @ bv).contiguous()
+        wq2, self.bq2 = fold_layernorm(self.attn2.to_q.weight, None, n2.weight, n2.bias)
+        self.wq2 = cv(wq2)
         self.wo2, self.bo2 = cv(self.attn2.to_out[0].weight), _f32(self.attn2.to_out[0].bias)
         self.kv = reg.add_kv(self.attn2.to_k, self.attn2.to_v)
-        self.ff.pack(reg, dtype)
+        self.ff.pack(reg, dtype, norm=self.norm3)
 
     def forward(self, x, g: Geom, ctx: StepContext):
-        a = _self_attention(ops.layernorm(x, *self.ln[0]), self.attn1, self.wqk, self.wv, g, ctx)
+        a = _self_attention(x, self.attn1, self.wqk, self.bqk, self.wv, self.norm1.eps, g, ctx)
         x = ops.gemm(a, self.wo1, bias=self.bo1, residual=x)
-        a = _cross_attention(ops.layernorm(x, *self.ln[1]), self.attn2, self.wq2, self.kv, g, ctx, temporal=False)
+        a = _cross_attention(x, self.attn2, self.wq2, self.bq2, self.norm2.eps, self.kv, g, ctx, temporal=False)
         x = ops.gemm(a, self.wo2, bias=self.bo2, residual=x)
-        return self.ff(ops.layernorm(x, *self.ln[2]), residual=x)
+        return self.ff(x, residual=x)
 
 
 class TemporalBasicTransformerBlock(_Packable):
@@ -401,26 +421,30 @@ class TemporalBasicTransformerBlock(_Packable):
         self.ff = FeedForward(time_mix_inner_dim)
 
     def pack(self, reg, dtype):
+        """All four LayerNorms are folded into their consumer GEMMs (see BasicTransformerBlock.pack)."""
         cv = lambda t: t.detach().to(dtype).contiguous()
-        self.ln = [(_f32(n.weight), _f32(n.bias)) for n in (self.norm_in, self.norm1, self.norm2, self.norm3)]
-        self.wqkv = cv(torch.cat([self.attn1.to_q.weight, self.attn1.to_k.weight, self.attn1.to_v.weight], 0))
+        n1, n2 = self.norm1, self.norm2
+        folded = [fold_layernorm(w.weight, None, n1.weight, n1.bias) for w in (self.attn1.to_q, self.attn1.to_k, self.attn1.to_v)]
+        self.wqkv = cv(torch.cat([w for w, _ in folded], 0))
+        self.bqkv = torch.cat([b for _, b in folded], 0).contiguous()
         self.wo1, self.bo1 = cv(self.attn1.to_out[0].weight), _f32(self.attn1.to_out[0].bias)
-        self.wq2 = cv(self.attn2.to_q.weight)
+        wq2, self.bq2 = fold_layernorm(self.attn2.to_q.weight, None, n2.weight, n2.bias)
+        self.wq2 = cv(wq2)
         self.wo2, self.bo2 = cv(self.attn2.to_out[0].weight), _f32(self.attn2.to_out[0].bias)
         self.kv = reg.add_kv(self.attn2.to_k, self.attn2.to_v)
-        self.ff_in.pack(reg, dtype)
-        self.ff.pack(reg, dtype)
+        self.ff_in.pack(reg, dtype, norm=self.norm_in)
+        self.ff.pack(reg, dtype, norm=self.norm3)
 
     def forward(self, x_spatial, pos_emb, g: Geom, ctx: StepContext, alpha: float):
         """x_spatial [M,C]; pos_emb fp32 [F,C].  Returns alpha*x_spatial + (1-alpha)*temporal(x_spatial + pos_emb)."""
         c = x_spatial.shape[1]
-        xs, n_in = ops.layernorm(x_spatial, *self.ln[0], rowvec=pos_emb, rows_per_vec=g.hw, nvec=g.frames)
-        t = self.ff_in(n_in, residual=xs)
-        qkv = ops.gemm(ops.layernorm(t, *self.ln[1]), self.wqkv)
+        xs = ops.add_rowvec(x_spatial, pos_emb, rows_per_vec=g.hw, nvec=g.frames)        # + frame-position embedding
+        t = self.ff_in(xs, residual=xs)
+        qkv = ops.gemm(t, self.wqkv, bias=self.bqkv, ln_fold=1, ln_eps=self.norm1.eps)
         a = torch.empty((g.m, c), dtype=t.dtype, device=t.device)
         ops.temporal_attention(qkv, a, batch=g.batch, frames=g.frames, hw=g.hw, heads=self.attn1.heads,
                                head_dim=self.attn1.dim_head)
         t = ops.gemm(a, self.wo1, bias=self.bo1, residual=t)
-        a = _cross_attention(ops.layernorm(t, *self.ln[2]), self.attn2, self.wq2, self.kv, g, ctx, temporal=True)
+        a = _cross_attention(t, self.attn2, self.wq2, self.bq2, self.norm2.eps, self.kv, g, ctx, temporal=True)
         t = ops.gemm(a, self.wo2, bias=self.bo2, residual=t)
-        return self.ff(ops.layernorm(t, *self.ln[3]), residual=t, blend=x_spatial, alpha=alpha)
+        return self.ff(t, residual=t, blend=x_spatial, alpha=alpha)
