@@ -108,3 +108,30 @@ def test_get_thisthat_sam_reads_the_reference_folder_layout(tmp_path):
     cfg["conditioning_channels"] = 1
     with pytest.raises(NotImplementedError):
         gm.get_thisthat_sam(cfg, str(tmp_path))
+
+
+def test_reference_example_point_sets_reproduce_their_committed_maps():
+    """The four annotated examples the reference ships (__assets__/Bridge_example/*/data.txt; inputs of
+    test_code/inference.py), committed as data in tests/golden/gesture_bridge.json together with checksums of the maps
+    (tests/golden/make_gesture_golden.py): frame slots, coordinates, value range and the exact rounded image."""
+    import hashlib
+    import json
+    doc = json.load(open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "gesture_bridge.json")))
+    assert len(doc["examples"]) == 4
+    for name, ex in doc["examples"].items():
+        pts = [tuple(p) for p in ex["points"]]
+        cond, frames, coords = gm.rasterise_points(pts, tuple(ex["org_hw"]), doc["height"], doc["width"], doc["frames"])
+        assert frames == ex["frames"] and [list(c) for c in coords] == ex["coords"], name
+        assert cond.shape == (doc["frames"], 3, doc["height"], doc["width"])
+        u8 = np.clip(cond * 255.0, 0, 255).round().astype(np.uint8)
+        assert hashlib.sha256(u8.tobytes()).hexdigest() == ex["map"]["sha256_u8"], name
+        np.testing.assert_allclose(float(cond.astype(np.float64).sum()), ex["map"]["sum"], rtol=1e-9)
+        # the first point is drawn red (B, G, R = 0, 0, 255), later ones green: inside the blob the other channels dip
+        f0, (v0, h0) = frames[0], coords[0]
+        sy, sx = doc["height"] / ex["org_hw"][0], doc["width"] / ex["org_hw"][1]
+        y, x = int(v0 * sy), int(h0 * sx)
+        assert cond[f0, 2, y, x] > 0.98 and cond[f0, 0, y, x] < 0.9 and cond[f0, 1, y, x] < 0.9, name
+        untouched = [f for f in range(doc["frames"]) if f not in frames]
+        assert float(np.abs(cond[untouched]).max()) == 0.0
+        flipped, _, _ = gm.rasterise_points(pts, tuple(ex["org_hw"]), doc["height"], doc["width"], doc["frames"], flip=True)
+        np.testing.assert_array_equal(flipped, cond[..., ::-1])

@@ -37,26 +37,31 @@ typedef __attribute__((ext_vector_type(2))) _Float16 ln_half2;
 typedef __attribute__((ext_vector_type(2))) __bf16 ln_bf162;
 template <typename Tag> __device__ __forceinline__ void ln_stat(const raw_u32x4_t& f, float& s, float& q);
 template <> __device__ __forceinline__ void ln_stat<bf16_tag>(const raw_u32x4_t& f, float& s, float& q) {
+  // (hipcc / ROCm 7.2 miscompiles __builtin_bit_cast(.., f[d]) on an ext-vector subscript inside a loop: every
+  // iteration reads element 0 -- tools/dot2_test.hip.  Copy the dwords to scalars first.)
   const ln_bf162 one = __builtin_bit_cast(ln_bf162, 0x3F803F80u);
+  const unsigned w[4] = {f.x, f.y, f.z, f.w};
 #pragma unroll
   for (int d = 0; d < 4; ++d) {
-    const ln_bf162 x = __builtin_bit_cast(ln_bf162, f[d]);
+    const ln_bf162 x = __builtin_bit_cast(ln_bf162, w[d]);
     s = __builtin_amdgcn_fdot2_f32_bf16(x, one, s, false);
     q = __builtin_amdgcn_fdot2_f32_bf16(x, x, q, false);
   }
 }
 template <> __device__ __forceinline__ void ln_stat<f16_tag>(const raw_u32x4_t& f, float& s, float& q) {
   const ln_half2 one = __builtin_bit_cast(ln_half2, 0x3C003C00u);
+  const unsigned w[4] = {f.x, f.y, f.z, f.w};
 #pragma unroll
   for (int d = 0; d < 4; ++d) {
-    const ln_half2 x = __builtin_bit_cast(ln_half2, f[d]);
+    const ln_half2 x = __builtin_bit_cast(ln_half2, w[d]);
     s = __builtin_amdgcn_fdot2(x, one, s, false);
     q = __builtin_amdgcn_fdot2(x, x, q, false);
   }
 }
 template <> __device__ __forceinline__ void ln_stat<f32_tag>(const raw_u32x4_t& f, float& s, float& q) {
+  const unsigned w[4] = {f.x, f.y, f.z, f.w};
 #pragma unroll
-  for (int d = 0; d < 4; ++d) { const float x = __uint_as_float(f[d]); s += x; q = fmaf(x, x, q); }
+  for (int d = 0; d < 4; ++d) { const float x = __uint_as_float(w[d]); s += x; q = fmaf(x, x, q); }
 }
 
 
