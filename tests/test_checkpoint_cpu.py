@@ -168,3 +168,26 @@ def test_clip_feature_extractor_matches_transformers():
     except Exception as e:          # an image-processor backend (PIL/torchvision) this image lacks
         pytest.skip(f"transformers CLIPImageProcessor unusable here: {e}")
     torch.testing.assert_close(ours, theirs, rtol=1e-5, atol=1e-5)
+
+
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
+def test_folded_layernorm_weights_keep_zero_row_sums_after_rounding(dtype):
+    """packing.fold_layernorm + zero_sum_round: Linear(LN(x)) == rstd * (x W''^T) + b' for the ROUNDED W'' and rows of x
+    with a large mean -- the rounded rows must still sum to ~0 or the row mean of x leaks into the output."""
+    from this_and_that_vdm_amd.packing import fold_layernorm, zero_sum_round
+    g = torch.Generator().manual_seed(0)
+    k, n = 320, 512
+    w, b = torch.randn(n, k, generator=g) * k ** -0.5, torch.randn(n, generator=g)
+    gamma, beta = torch.rand(k, generator=g) + 0.5, torch.randn(k, generator=g)
+    wf, bf = fold_layernorm(w, b, gamma, beta)
+    plain, zs = wf.to(dtype), zero_sum_round(wf, dtype)
+    assert zs.dtype == dtype
+    r_plain, r_zs = plain.double().sum(1).abs().max(), zs.double().sum(1).abs().max()
+    assert r_zs <= 1e-5 and r_zs < r_plain / 100, (float(r_plain), float(r_zs))
+    # moving an element to its OTHER rounding neighbour costs at most 1.5 ulp of error against 0.5 for plain rounding
+    assert (zs.double() - wf.double()).abs().max() <= 3.01 * (plain.double() - wf.double()).abs().max()
+    x = torch.randn(64, k, generator=g) + 25.0                   # row mean = 25 sigma
+    ref = torch.nn.functional.linear(torch.nn.functional.layer_norm(x, (k,), gamma, beta, 1e-5), w, b)
+    rstd = 1.0 / torch.sqrt(x.var(1, unbiased=False, keepdim=True) + 1e-5)
+    err = lambda wq: float(((rstd * (x.double() @ wq.double().T) + bf) - ref).abs().max())
+    assert err(zs) < err(plain) / 10 and err(zs) < 0.05, (err(zs), err(plain))

@@ -213,3 +213,56 @@ def test_guess_mode_without_cfg_uses_logspace_scales():
         DenoiseLoop(p_unet, p_cn).begin(**dict(kw, image_latents=inp["image_latents"], encoder_hidden_states=inp["encoder_hidden_states"],
                                                added_time_ids=inp["added_time_ids"], guidance_scale=inp["guidance_scale"]),
                                         guess_mode=True)
+
+
+@torch.no_grad()
+def test_captured_graphs_survive_scratch_growth_and_weight_reloads():
+    """Captured hipGraphs hold raw pointers.  (1) VL request -> VGL request -> a larger request whose split-K GEMMs outgrow
+    the scratch buffer -> the first VL loop again: its graph must still run on valid memory and reproduce its first result
+    bit for bit.  (2) load_state_dict between two requests on the same loop object: the packed weights are rebuilt, so the
+    loop must re-capture (pack generation in its key) and match an eager run on the new weights."""
+    if not torch.cuda.is_available():
+        pytest.skip("needs a GPU")
+    from this_and_that_vdm_amd import ops
+    from this_and_that_vdm_amd.svd.denoise import DenoiseLoop
+    from this_and_that_vdm_amd.svd.scheduling_euler_discrete import EulerDiscreteScheduler
+    from this_and_that_vdm_amd.utils.synthetic import fill_parameters_, synthetic_inputs
+    p_unet, p_cn, _, _ = build_pair("tiny_vgl", torch.float16, "cuda:0", True)
+    sched = EulerDiscreteScheduler()
+    sched.set_timesteps(3)
+
+    def kw(h, w, with_cn, seed=3):
+        inp = synthetic_inputs(2, 4, h, w, ctx_tokens=5, ctx_dim=64, seed=seed)
+        return dict(latents=inp["latents"], image_latents=inp["image_latents"], encoder_hidden_states=inp["encoder_hidden_states"],
+                    added_time_ids=inp["added_time_ids"], guidance_scale=inp["guidance_scale"], sigmas=sched.sigmas,
+                    timesteps=sched.timesteps, controlnet_cond=inp["gesture_latents"] if with_cn else None)
+
+    floor, ops.WS_FLOOR_BYTES = ops.WS_FLOOR_BYTES, 1 << 12        # tiny scratch floor: the larger request MUST outgrow it
+    try:
+        retired0 = len(ops._WS_RETIRED)
+        vl = DenoiseLoop(p_unet, None, use_graph=True)
+        first = vl.begin(**kw(8, 16, False)).run().clone()
+        vgl = DenoiseLoop(p_unet, p_cn, use_graph=True)
+        vgl_first = vgl.begin(**kw(8, 16, True)).run().clone()
+        big = DenoiseLoop(p_unet, p_cn, use_graph=True)
+        big.begin(**kw(24, 40, True)).run()
+        torch.cuda.synchronize()
+        grew = len(ops._WS_RETIRED) > retired0
+        print("split-K scratch outgrown by the larger request:", grew, "retired buffers:", len(ops._WS_RETIRED) - retired0)
+        assert grew, "the larger request was meant to outgrow the split-K scratch (tiny floor)"
+        again = vl.begin(**kw(8, 16, False)).run().clone()
+        assert torch.equal(again, first), "VL graph after scratch growth must reproduce its first result"
+        assert torch.equal(vgl.begin(**kw(8, 16, True)).run(), vgl_first)
+    finally:
+        ops.WS_FLOOR_BYTES = floor
+    # (2) new weights under a live loop object
+    gen0 = p_unet._pack_gen
+    before = vl.begin(**kw(8, 16, False)).run().clone()
+    sd = {k: v.clone() for k, v in p_unet.state_dict().items()}
+    fill_parameters_(p_unet, "other-unet.", round_to=torch.float16)
+    after = vl.begin(**kw(8, 16, False)).run().clone()
+    assert p_unet._pack_gen > gen0 and not torch.equal(after, before), "the reloaded weights must take effect"
+    eager = DenoiseLoop(p_unet, None, use_graph=False).begin(**kw(8, 16, False)).run().clone()
+    assert torch.equal(after, eager), "re-captured graph must equal eager launches on the new weights"
+    p_unet.load_state_dict(sd)
+    assert torch.equal(vl.begin(**kw(8, 16, False)).run(), before), "restoring the weights restores the result"

@@ -249,13 +249,13 @@ def test_gemm_fused_layernorm_rows(ops, dtype, m, c, n):
     """Linear(LayerNorm(x)) with the LayerNorm folded into the GEMM (tt_gemm ln_fold = 1): x reaches the kernel
     UN-normalised, gamma/beta live in the centred weights / bias (packing.fold_layernorm), 1/sigma comes from the operand
     fragments inside the K loop.  Rows carry a mean offset of ~1 sigma, as hidden states do."""
-    from this_and_that_vdm_amd.packing import fold_layernorm
+    from this_and_that_vdm_amd.packing import fold_layernorm, zero_sum_round
     x = (rnd(m, c, dtype=torch.float32, seed=1, scale=1.5) + rnd(m, 1, dtype=torch.float32, seed=9, scale=1.5)).to(dtype)
     w, b = rnd(n, c, dtype=dtype, seed=2, scale=c ** -0.5), rnd(n, dtype=torch.float32, seed=3)
     g, be = rnd(c, dtype=torch.float32, seed=4, scale=0.2) + 1, rnd(c, dtype=torch.float32, seed=5, scale=0.3)
     res = rnd(m, n, dtype=dtype, seed=6)
     wf, bf = fold_layernorm(w.float(), b, g, be)
-    out = ops.gemm(x.cuda(), wf.to(dtype).cuda(), bias=bf.cuda(), residual=res.cuda(), ln_fold=1, ln_eps=1e-5)
+    out = ops.gemm(x.cuda(), zero_sum_round(wf, dtype).cuda(), bias=bf.cuda(), residual=res.cuda(), ln_fold=1, ln_eps=1e-5)
     ref = F.linear(F.layer_norm(x.float(), (c,), g, be, 1e-5), w.float(), b) + res.float()
     # the folded weights are rounded AFTER the multiplication by gamma: allow their 2^-9 / 2^-12 relative rounding
     close(out, ref, dtype, scale=2.0) if dtype != torch.float16 else torch.testing.assert_close(out.float().cpu(), ref, rtol=2e-3, atol=2e-3)
@@ -263,7 +263,7 @@ def test_gemm_fused_layernorm_rows(ops, dtype, m, c, n):
 
 @pytest.mark.parametrize("dtype", DTYPES)
 def test_gemm_fused_layernorm_geglu_and_columns(ops, dtype):
-    from this_and_that_vdm_amd.packing import fold_layernorm, pack_geglu
+    from this_and_that_vdm_amd.packing import fold_layernorm, pack_geglu, zero_sum_round
     m, c = 700, 320
     x = (rnd(m, c, dtype=torch.float32, seed=1) + 0.5).to(dtype)
     g, be = rnd(c, dtype=torch.float32, seed=4, scale=0.2) + 1, rnd(c, dtype=torch.float32, seed=5, scale=0.3)
@@ -272,7 +272,7 @@ def test_gemm_fused_layernorm_geglu_and_columns(ops, dtype):
     # GEGLU feed-forward projection (FeedForward.net[0]) behind norm3
     w, b = rnd(8 * c, c, dtype=dtype, seed=2, scale=c ** -0.5), rnd(8 * c, dtype=torch.float32, seed=3)
     wf, bf = fold_layernorm(w.float(), b, g, be)
-    wp, bp = pack_geglu(wf.to(dtype), bf)
+    wp, bp = pack_geglu(zero_sum_round(wf, dtype), bf)
     out = ops.gemm(x.cuda(), wp.cuda(), bias=bp.cuda(), geglu=True, ln_fold=1, ln_eps=1e-5)
     h = xn @ w.float().T + b
     torch.testing.assert_close(out.float().cpu(), h[:, :4 * c] * F.gelu(h[:, 4 * c:]), **tol)
@@ -282,13 +282,13 @@ def test_gemm_fused_layernorm_geglu_and_columns(ops, dtype):
     wv = rnd(c, c, dtype=dtype, seed=7, scale=c ** -0.5)
     wvf, bv = fold_layernorm(wv.float(), None, g, be)
     vt = torch.zeros(c, nseq * hwp, dtype=dtype, device="cuda")
-    ops.gemm(wvf.to(dtype).cuda(), x.cuda(), out=vt, out_col_pad=(hw, hwp), ln_fold=2, ln_eps=1e-5)
+    ops.gemm(zero_sum_round(wvf, dtype).cuda(), x.cuda(), out=vt, out_col_pad=(hw, hwp), ln_fold=2, ln_eps=1e-5)
     ref = (wv.float() @ xn.T - bv[:, None]).reshape(c, nseq, hw)
     got = vt.float().cpu().reshape(c, nseq, hwp)
     torch.testing.assert_close(got[:, :, :hw], ref, **tol)
     assert float(got[:, :, hw:].abs().max()) == 0.0
     # ... and without padding (the non-transposing epilogue path)
-    vt2 = ops.gemm(wvf.to(dtype).cuda(), x.cuda(), ln_fold=2, ln_eps=1e-5)
+    vt2 = ops.gemm(zero_sum_round(wvf, dtype).cuda(), x.cuda(), ln_fold=2, ln_eps=1e-5)
     torch.testing.assert_close(vt2.float().cpu(), wv.float() @ xn.T - bv[:, None], **tol)
 
 

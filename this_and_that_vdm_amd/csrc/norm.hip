@@ -19,8 +19,8 @@ __host__ __device__ inline int gn_rows_per_chunk(int C) {
 // The block that publishes the LAST partial of a statistics group (image, or `fpg` consecutive images for the temporal
 // ResBlocks) also reduces them -- in a fixed order, so results do not depend on which block that is -- and writes the
 // per-(image, channel) scale / shift: no separate finalize launch.  Hand-off between workgroups follows the
-// placement-independent protocol of the CDNA guide (section 6, guideline 16): partial stores -> s_waitcnt vmcnt(0) ->
-// barrier -> one lane: agent-scope release fence, asm vmcnt(0), relaxed agent-scope ticket; the last arriver: one
+// placement-independent protocol of the CDNA guide (section 6, guideline 16, write-through form): sc1 partial stores ->
+// s_waitcnt vmcnt(0) in the storing wave -> barrier -> one lane: relaxed agent-scope ticket; the last arriver: one
 // agent-scope acquire fence -> barrier -> plain loads.  `counters[group]` must be 0 on entry and is 0 again on exit.
 template <typename Tag>
 __global__ void gn_partial_kernel(const char* x0, int c0, const char* x1, int c1, int hw, int chunks, double* ws,
@@ -74,7 +74,10 @@ __global__ void gn_partial_kernel(const char* x0, int c0, const char* x1, int c1
     for (int r = 0; r < rpb; ++r)
       for (int c = tid * cpg; c < (tid + 1) * cpg; ++c) { a += (double)psum[r * C + c]; b += (double)psq[r * C + c]; }
     double* o = ws + (((long)img * chunks + chunk) * GN_GROUPS + tid) * 2;
-    o[0] = a; o[1] = b;
+    // write-through (sc1) stores: the partial is visible device-wide once vmcnt drains, no release fence needed -- a
+    // per-block `buffer_wbl2` made this kernel 2-3x slower than partial + finalize as two launches
+    __hip_atomic_store(o, a, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    __hip_atomic_store(o + 1, b, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   }
   // ---- publish; the last arriver of this statistics group finalises it
   const int ig = img / fpg;
@@ -82,8 +85,6 @@ __global__ void gn_partial_kernel(const char* x0, int c0, const char* x1, int c1
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __syncthreads();
   if (tid == 0) {
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     const unsigned ticket = __hip_atomic_fetch_add(counters + ig, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     *flag = ticket == (unsigned)(fpg * chunks) - 1u;
   }

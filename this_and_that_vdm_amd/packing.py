@@ -41,12 +41,44 @@ def pad_rows(w: torch.Tensor, multiple: int) -> torch.Tensor:
     return out
 
 
+def zero_sum_round(w: torch.Tensor, dtype: torch.dtype) -> torch.Tensor:
+    """Round the rows of ``w`` (fp32/fp64, each summing to ~0) to ``dtype`` such that every ROUNDED row still sums to zero
+    (to ~1e-6 of an ulp-sized weight instead of ~sqrt(K) ulps): plain rounding leaves a residual
+    r_n = sum_k round(w_nk) != 0 and the fused LayerNorm GEMM would then add  mean(x) * r_n * rstd  to its output -- an error
+    that grows with the row mean of x.  Greedy mixed-radix correction, binade by binade from the coarsest spacing to the
+    finest: within a binade every element has the same spacing u, so round(r / u) of them (at most all) are moved by one
+    ulp -- i.e. to their other rounding neighbour -- towards cancelling what is left of the residual r.
+    fp32: returned as is (the residual is ~1e-7 of a weight)."""
+    if dtype == torch.float32:
+        return w.float().contiguous()
+    mant, emin = {torch.bfloat16: (7, -126), torch.float16: (10, -14)}[dtype]
+    q = w.detach().to(dtype).double()
+    _, e = torch.frexp(q.abs())                               # |q| = m * 2^e, m in [0.5, 1)
+    e = torch.clamp(e - 1, min=emin)                          # binade exponent (subnormals share the lowest one)
+    nz = q != 0
+    r = q.sum(dim=1)                                          # residual of every row, fp64 (exact: all terms are dyadic)
+    lo = int(e[nz].min()) if bool(nz.any()) else 0
+    hi = int(e[nz].max()) if bool(nz.any()) else -1
+    for lvl in range(hi, max(lo, hi - 48) - 1, -1):           # <= 49 levels of O(N K) vector work, once per layer at load
+        u = 2.0 ** (lvl - mant)
+        mask = nz & (e == lvl)
+        cnt = mask.sum(dim=1)
+        n = torch.minimum(torch.round(r / u).abs(), cnt.double()) * torch.sign(r)
+        sel = mask & (torch.cumsum(mask, dim=1) <= n.abs()[:, None])
+        q = q - sel.double() * (torch.sign(n) * u)[:, None]
+        r = r - n * u
+    out = q.to(dtype)
+    assert torch.equal(out.double(), q), "zero_sum_round: a corrected value is not representable"
+    return out.contiguous()
+
+
 def fold_layernorm(weight: torch.Tensor, bias, gamma: torch.Tensor, beta: torch.Tensor):
     """Fold the affine part of ``nn.LayerNorm`` (gamma, beta) into the ``nn.Linear`` that consumes it, for tt_gemm's
     ``ln_fold`` (include/ttvdm.h):   Linear(LN(x)) = rstd * ((x - mean) (W*gamma)^T) + (W beta + bias).
     Returns (W'', b') in fp32 with  W'' = W*gamma - rowmean_k(W*gamma):  rows that sum to zero make
     x W''^T == (x - mean) W''^T for ANY x (the row mean of x multiplies sum_k W''[n,k] = 0), so the kernel can run on the
     raw activations and only has to scale each output row by rstd, which it measures itself from the operand stream.
+    Round W'' to a 16-bit storage type with ``zero_sum_round`` (keeps the zero row sums exact), not with ``.to(dtype)``.
     weight [N, K]; bias [N] or None; gamma, beta [K]."""
     w = weight.detach().float()
     wg = w * gamma.detach().float()[None, :]

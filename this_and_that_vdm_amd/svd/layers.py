@@ -18,7 +18,7 @@ import torch
 import torch.nn as nn
 
 from .. import ops
-from ..packing import fold_layernorm, pack_conv1x1, pack_conv3x3, pack_geglu, pack_tconv3
+from ..packing import fold_layernorm, pack_conv1x1, pack_conv3x3, pack_geglu, pack_tconv3, zero_sum_round
 
 
 @dataclass
@@ -326,6 +326,7 @@ class FeedForward(_Packable):
         self.ln_fold, self.ln_eps = 0, 1e-5
         if norm is not None:
             w, b = fold_layernorm(w, b, norm.weight, norm.bias)
+            w = zero_sum_round(w, dtype)
             self.ln_fold, self.ln_eps = 1, norm.eps
         self.wg, self.bg = pack_geglu(w.to(dtype), _f32(b))
         self.w2, self.b2 = self.net[2].weight.detach().to(dtype).contiguous(), _f32(self.net[2].bias)
@@ -379,16 +380,17 @@ class BasicTransformerBlock(_Packable):
         Wv beta added to every key's value; softmax rows sum to 1, so it passes through attention unchanged and is added to
         to_out's bias (Wo (Wv beta))."""
         cv = lambda t: t.detach().to(dtype).contiguous()
+        zr = lambda t: zero_sum_round(t, dtype)              # folded weights: rounded with exact zero row sums
         n1, n2 = self.norm1, self.norm2
         wq, bq = fold_layernorm(self.attn1.to_q.weight, None, n1.weight, n1.bias)
         wk, bk = fold_layernorm(self.attn1.to_k.weight, None, n1.weight, n1.bias)
         wv, bv = fold_layernorm(self.attn1.to_v.weight, None, n1.weight, n1.bias)
-        self.wqk, self.bqk = cv(torch.cat([wq, wk], 0)), torch.cat([bq, bk], 0).contiguous()
-        self.wv = cv(wv)
+        self.wqk, self.bqk = zr(torch.cat([wq, wk], 0)), torch.cat([bq, bk], 0).contiguous()
+        self.wv = zr(wv)
         self.wo1 = cv(self.attn1.to_out[0].weight)
         self.bo1 = (_f32(self.attn1.to_out[0].bias) + self.wo1.float() @ bv).contiguous()
         wq2, self.bq2 = fold_layernorm(self.attn2.to_q.weight, None, n2.weight, n2.bias)
-        self.wq2 = cv(wq2)
+        self.wq2 = zr(wq2)
         self.wo2, self.bo2 = cv(self.attn2.to_out[0].weight), _f32(self.attn2.to_out[0].bias)
         self.kv = reg.add_kv(self.attn2.to_k, self.attn2.to_v)
         self.ff.pack(reg, dtype, norm=self.norm3)
@@ -423,13 +425,14 @@ class TemporalBasicTransformerBlock(_Packable):
     def pack(self, reg, dtype):
         """All four LayerNorms are folded into their consumer GEMMs (see BasicTransformerBlock.pack)."""
         cv = lambda t: t.detach().to(dtype).contiguous()
+        zr = lambda t: zero_sum_round(t, dtype)
         n1, n2 = self.norm1, self.norm2
         folded = [fold_layernorm(w.weight, None, n1.weight, n1.bias) for w in (self.attn1.to_q, self.attn1.to_k, self.attn1.to_v)]
-        self.wqkv = cv(torch.cat([w for w, _ in folded], 0))
+        self.wqkv = zr(torch.cat([w for w, _ in folded], 0))
         self.bqkv = torch.cat([b for _, b in folded], 0).contiguous()
         self.wo1, self.bo1 = cv(self.attn1.to_out[0].weight), _f32(self.attn1.to_out[0].bias)
         wq2, self.bq2 = fold_layernorm(self.attn2.to_q.weight, None, n2.weight, n2.bias)
-        self.wq2 = cv(wq2)
+        self.wq2 = zr(wq2)
         self.wo2, self.bo2 = cv(self.attn2.to_out[0].weight), _f32(self.attn2.to_out[0].bias)
         self.kv = reg.add_kv(self.attn2.to_k, self.attn2.to_v)
         self.ff_in.pack(reg, dtype, norm=self.norm_in)
