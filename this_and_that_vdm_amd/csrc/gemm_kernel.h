@@ -392,6 +392,11 @@ void gemm_kernel(const GemmP p) {
 #pragma unroll
       for (int j = 0; j < FN; ++j)
         acc[i][j] = Cvt<Tag>::mfma32(make_uint4(bf[j].x, bf[j].y, bf[j].z, bf[j].w), make_uint4(af[i].x, af[i].y, af[i].z, af[i].w), acc[i][j]);
+    // The fragment registers are written by raw asm ds_reads whose data lands later (cdna guide 5.7 item 1).  If the
+    // scheduler sinks the statistics VALU below the NEXT raw read of the same fragment set, the two values are live at once,
+    // the new read gets other registers and a v_mov copies them back at the loop edge -- before the data has landed
+    // (NaNs under load, measured).  Pin everything that reads the fragments in front of whatever follows.
+    if constexpr (LN != 0) __builtin_amdgcn_sched_barrier(0);
   };
 
   // residual operands of every (row, quad) this lane will finish (epilogue layout, see below): ONE batch of loads.
@@ -467,7 +472,11 @@ void gemm_kernel(const GemmP p) {
     raw_u32x4_t afA[FM], bfA[FN], afB[FM], bfB[FN];
     read_frags(lds_base, 0, afA, bfA);
     int slot = 0, fill = NST - 1;             // slot of tile kt ; slot the next staged tile goes to
-    for (int kt = 0; kt < KT; ++kt) {
+    // The last tile is peeled: inside the steady loop set A is (re)defined by the raw read at ONE program point on every
+    // path, so no value merge of "old fragments / new fragments" exists and hipcc has no reason to copy raw-read registers
+    // (a copy would run before the data has landed: cdna guide 5.7 item 1).
+    auto tile = [&](int kt, auto last_tag) {
+      constexpr bool LAST = decltype(last_tag)::value;
       const unsigned sa = lds_base + slot * STAGE;
       const int nslot = slot + 1 == NST ? 0 : slot + 1;
 #pragma unroll
@@ -478,7 +487,7 @@ void gemm_kernel(const GemmP p) {
         if (ks + 2 < KS) {
           read_frags(sa, ks + 2, afA, bfA);
           lds_wait<NF>();                     // set B has landed
-        } else if (kt + 1 < KT) {
+        } else if constexpr (!LAST) {
           // tile kt+1 must have landed; tiles kt+2 .. min(KT-1, kt+NST-2) may stay in flight
           wait_tiles<G>(min(KT - 2 - kt, NST - 3));
           __builtin_amdgcn_s_barrier();       // all waves: tile kt+1 visible, tile kt-1's slot free
@@ -493,7 +502,9 @@ void gemm_kernel(const GemmP p) {
       }
       slot = nslot;
       fill = fill + 1 == NST ? 0 : fill + 1;
-    }
+    };
+    for (int kt = 0; kt + 1 < KT; ++kt) tile(kt, std::false_type{});
+    tile(KT - 1, std::true_type{});
   }
 
   // ---- fused LayerNorm: 1/sigma of the operand rows from the sums gathered beside the MFMAs (the two lane halves hold the
