@@ -6,8 +6,9 @@ channel/head configuration) -- and one block of configs[4] (64x112 latents):
   * TWO full steps against the fp32 oracle on identical (bf16-representable) weights, in all three storage modes:
       TT_F32  every element of the UNet output (public forward(), ControlNet residuals included) and of the latents after
               two fused steps inside the north-star tolerance rtol 1e-3 / atol 1e-4 (torch.testing.assert_close);
-      fp16    relative L2 of what the networks contributed to the latents <= 8e-3, cosine >= 0.9999;
-      bf16    relative L2 <= 4e-2, cosine >= 0.999 (errors of step 1 feed step 2: looser than the one-step figure);
+      fp16    relative L2 of what the networks contributed to the latents <= 4e-3 (measured 1.8e-3 / 1.4e-3 after step 1 / 2),
+              cosine >= 0.99999;
+      bf16    relative L2 <= 3e-2 (measured 1.45e-2 / 1.15e-2), cosine >= 0.9995;
     the fraction of elements inside the north-star tolerance is printed for the 16-bit modes;
   * one L0 TransformerSpatioTemporalModel (C = 320, 5 heads x 64, hw = 64x112 = 7168 tokens per frame, 14 frames: the
     "spatio-temporal-attention block" of BASELINE config 5) against the oracle: TT_F32 at the north-star tolerance,
@@ -151,7 +152,7 @@ def test_full_size_f32_mode_meets_the_north_star_tolerance(full):
     assert_north_star(lat2.reshape(ref["lat2"].shape), ref["lat2"], "latents after fused step 2")
 
 
-@pytest.mark.parametrize("dtype,rel,cos", [(torch.float16, 8e-3, 0.9999), (torch.bfloat16, 4e-2, 0.999)])
+@pytest.mark.parametrize("dtype,rel,cos", [(torch.float16, 4e-3, 0.99999), (torch.bfloat16, 3e-2, 0.9995)])
 @torch.no_grad()
 def test_full_size_two_steps_match_oracle(full, dtype, rel, cos):
     ref, inp = full["ref"], full["inp"]

@@ -268,7 +268,9 @@ def test_gemm_fused_layernorm_geglu_and_columns(ops, dtype):
     x = (rnd(m, c, dtype=torch.float32, seed=1) + 0.5).to(dtype)
     g, be = rnd(c, dtype=torch.float32, seed=4, scale=0.2) + 1, rnd(c, dtype=torch.float32, seed=5, scale=0.3)
     xn = F.layer_norm(x.float(), (c,), g, be, 1e-5)
-    tol = dict(rtol=2e-3, atol=2e-3) if dtype == torch.float16 else dict(rtol=TOL[dtype]["rtol"], atol=TOL[dtype]["atol"] * (2 if dtype == torch.bfloat16 else 1))
+    # fp16: the folded weights are rounded AFTER the multiplication by gamma and up to 1.5 ulp away from it (zero-sum
+    # rounding); value * gelu(gate) multiplies two such ~1e-3 errors by O(3) operands: rtol = atol = 5e-3
+    tol = dict(rtol=5e-3, atol=5e-3) if dtype == torch.float16 else dict(rtol=TOL[dtype]["rtol"], atol=TOL[dtype]["atol"] * (2 if dtype == torch.bfloat16 else 1))
     # GEGLU feed-forward projection (FeedForward.net[0]) behind norm3
     w, b = rnd(8 * c, c, dtype=dtype, seed=2, scale=c ** -0.5), rnd(8 * c, dtype=torch.float32, seed=3)
     wf, bf = fold_layernorm(w.float(), b, g, be)
