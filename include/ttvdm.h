@@ -148,15 +148,9 @@ int tt_temporal_attention(const void* qkv, int64_t ldqkv, void* out, int64_t ldo
  *     y = x*scale + shift  ==  (x-mean)*rstd*gamma + beta
  * ---------------------------------------------------------------------------------------------- */
 size_t tt_groupnorm_ws_bytes(int32_t nimg, int32_t hw, int32_t c);
-/* `counters`: TT_GN_MAX_GROUPS uint32 arrival counters, all 0 on entry and all 0 again when the call has executed (the
- * block that publishes the last partial sum of a statistics group reduces them and writes scale/shift: ONE launch).  A
- * caller keeps one zero-initialised array per stream; calls on one stream may share it (they are ordered), calls on
- * concurrent streams may not. */
-#define TT_GN_MAX_GROUPS 1024
 int tt_groupnorm_stats(const void* x0, int32_t c0, const void* x1, int32_t c1, int32_t nimg, int32_t hw,
                        int32_t frames_per_group, const float* gamma, const float* beta, float eps,
-                       float* scale, float* shift, void* ws, size_t ws_bytes, uint32_t* counters, int32_t dtype,
-                       tt_stream_t stream);
+                       float* scale, float* shift, void* ws, size_t ws_bytes, int32_t dtype, tt_stream_t stream);
 /* y[n,p,0:c0+c1] = act(x*scale+shift), act = SiLU if silu else identity; y has row stride ldy (>= c0+c1,
  * extra columns untouched). */
 int tt_groupnorm_apply(const void* x0, int32_t c0, const void* x1, int32_t c1, int32_t nimg, int32_t hw,

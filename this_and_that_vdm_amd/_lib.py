@@ -56,7 +56,7 @@ SIGNATURES = {
     "tt_attention": (C.c_int, [C.POINTER(TtAttnArgs), _vp]),
     "tt_temporal_attention": (C.c_int, [_vp, _i64, _vp, _i64, _i32, _i32, _i32, _i32, _i32, _i32, _vp]),
     "tt_groupnorm_ws_bytes": (_sz, [_i32, _i32, _i32]),
-    "tt_groupnorm_stats": (C.c_int, [_vp, _i32, _vp, _i32, _i32, _i32, _i32, _vp, _vp, _f32, _vp, _vp, _vp, _sz, _vp, _i32, _vp]),
+    "tt_groupnorm_stats": (C.c_int, [_vp, _i32, _vp, _i32, _i32, _i32, _i32, _vp, _vp, _f32, _vp, _vp, _vp, _sz, _i32, _vp]),
     "tt_groupnorm_apply": (C.c_int, [_vp, _i32, _vp, _i32, _i32, _i32, _vp, _vp, _i32, _vp, _i64, _i32, _vp]),
     "tt_layernorm": (C.c_int, [_vp, _i64, _i32, _i32, _vp, _vp, _f32, _vp, _i32, _i32, _vp, _vp, _i64, _i32, _vp]),
     "tt_small_linear": (C.c_int, [_vp, _i64, _i32, _i32, _vp, _i64, _i32, _vp, _i32, _i32, _i32, _vp, _i64, _i32, _vp]),

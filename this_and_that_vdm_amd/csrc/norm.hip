@@ -15,17 +15,9 @@ __host__ __device__ inline int gn_rows_per_chunk(int C) {
   return rows > 128 ? 128 : rows;
 }
 
-// partial sums per (image, row-chunk, group): ws[((img*chunks + chunk)*32 + g)*2 + {0,1}] (double).
-// The block that publishes the LAST partial of a statistics group (image, or `fpg` consecutive images for the temporal
-// ResBlocks) also reduces them -- in a fixed order, so results do not depend on which block that is -- and writes the
-// per-(image, channel) scale / shift: no separate finalize launch.  Hand-off between workgroups follows the
-// placement-independent protocol of the CDNA guide (section 6, guideline 16, write-through form): sc1 partial stores ->
-// s_waitcnt vmcnt(0) in the storing wave -> barrier -> one lane: relaxed agent-scope ticket; the last arriver: one
-// agent-scope acquire fence -> barrier -> plain loads.  `counters[group]` must be 0 on entry and is 0 again on exit.
+// partial sums per (image, row-chunk, group): ws[((img*chunks + chunk)*32 + g)*2 + {0,1}] (double)
 template <typename Tag>
-__global__ void gn_partial_kernel(const char* x0, int c0, const char* x1, int c1, int hw, int chunks, double* ws,
-                                  int fpg, const float* gamma, const float* beta, float eps, float* scale, float* shift,
-                                  unsigned* counters, int flag_off) {
+__global__ void gn_partial_kernel(const char* x0, int c0, const char* x1, int c1, int hw, int chunks, double* ws) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   // per-(row-lane, channel) partial sums, reduced in a fixed order: results are bit-reproducible
   const int C = c0 + c1, cv = C >> 3;    // 8-channel vectors per row
@@ -74,52 +66,37 @@ __global__ void gn_partial_kernel(const char* x0, int c0, const char* x1, int c1
     for (int r = 0; r < rpb; ++r)
       for (int c = tid * cpg; c < (tid + 1) * cpg; ++c) { a += (double)psum[r * C + c]; b += (double)psq[r * C + c]; }
     double* o = ws + (((long)img * chunks + chunk) * GN_GROUPS + tid) * 2;
-    // write-through (sc1) stores: the partial is visible device-wide once vmcnt drains, no release fence needed -- a
-    // per-block `buffer_wbl2` made this kernel 2-3x slower than partial + finalize as two launches
-    __hip_atomic_store(o, a, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    __hip_atomic_store(o + 1, b, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    o[0] = a; o[1] = b;
   }
-  // ---- publish; the last arriver of this statistics group finalises it
-  const int ig = img / fpg;
-  unsigned* flag = (unsigned*)(smem + flag_off);
-  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-  __syncthreads();
-  if (tid == 0) {
-    const unsigned ticket = __hip_atomic_fetch_add(counters + ig, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    *flag = ticket == (unsigned)(fpg * chunks) - 1u;
-  }
-  __syncthreads();
-  if (!*flag) return;
-  if (tid == 0) {
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
-    __hip_atomic_store(counters + ig, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);      // ready for the next launch
-  }
-  __syncthreads();
-  // fixed-order reduction of the group's fpg*chunks partials: `slices` strided partial sums, combined in slice order
-  double* s_a = (double*)smem;                 // [slices][32]   (the per-channel scratch above is dead now)
-  const int slices = nthr / GN_GROUPS;
-  double* s_b = s_a + slices * GN_GROUPS;
-  float* s_mean = (float*)(s_b + slices * GN_GROUPS);
-  float* s_rstd = s_mean + GN_GROUPS;
+}
+
+// one block per statistics group-set: (image-group ig) -> images [ig*fpg, (ig+1)*fpg).
+// 1024 threads = 32 groups x 32 slices; each slice sums a strided subset of the (frame, chunk) partials, then the
+// 32 slices are combined in a fixed order (deterministic).  (The cross-frame statistics of the temporal ResBlocks reduce
+// frames x chunks ~ 500 partials in 2 blocks: the slice count is what bounds this kernel's latency.)
+constexpr int GN_SLICES = 32;
+__global__ __launch_bounds__(1024) void gn_finalize_kernel(const double* ws, int chunks, int hw, int C, int fpg,
+                                                          const float* gamma, const float* beta, float eps,
+                                                          float* scale, float* shift) {
+  __shared__ double s_a[GN_SLICES][GN_GROUPS], s_b[GN_SLICES][GN_GROUPS];
+  __shared__ float s_mean[GN_GROUPS], s_rstd[GN_GROUPS];
+  const int ig = blockIdx.x, tid = threadIdx.x;
+  const int g = tid & 31, slice = tid >> 5;
   {
-    const int g = tid & 31, slice = tid >> 5;
+    double a = 0.0, b = 0.0;
     const int total = fpg * chunks;
     const double* base = ws + ((long)ig * fpg * chunks) * GN_GROUPS * 2;
-    double a0 = 0.0, b0 = 0.0, a1 = 0.0, b1 = 0.0, a2 = 0.0, b2 = 0.0, a3 = 0.0, b3 = 0.0;   // 4 loads in flight per thread
-    int i = slice;
-    for (; i + 3 * slices < total; i += 4 * slices) {
-      const double* o0 = base + ((long)i * GN_GROUPS + g) * 2;
-      const double* o1 = o0 + (long)slices * GN_GROUPS * 2, *o2 = o1 + (long)slices * GN_GROUPS * 2, *o3 = o2 + (long)slices * GN_GROUPS * 2;
-      a0 += o0[0]; b0 += o0[1]; a1 += o1[0]; b1 += o1[1]; a2 += o2[0]; b2 += o2[1]; a3 += o3[0]; b3 += o3[1];
+    for (int i = slice; i < total; i += GN_SLICES) {
+      const double* o = base + ((long)i * GN_GROUPS + g) * 2;
+      a += o[0]; b += o[1];
     }
-    for (; i < total; i += slices) { const double* o = base + ((long)i * GN_GROUPS + g) * 2; a0 += o[0]; b0 += o[1]; }
-    s_a[slice * GN_GROUPS + g] = (a0 + a1) + (a2 + a3);
-    s_b[slice * GN_GROUPS + g] = (b0 + b1) + (b2 + b3);
+    s_a[slice][g] = a; s_b[slice][g] = b;
   }
   __syncthreads();
   if (tid < GN_GROUPS) {
     double a = 0.0, b = 0.0;
-    for (int sl = 0; sl < slices; ++sl) { a += s_a[sl * GN_GROUPS + tid]; b += s_b[sl * GN_GROUPS + tid]; }
+#pragma unroll
+    for (int s = 0; s < GN_SLICES; ++s) { a += s_a[s][tid]; b += s_b[s][tid]; }
     const double cnt = (double)fpg * hw * (C / GN_GROUPS);
     const double mean = a / cnt;
     double var = b / cnt - mean * mean;
@@ -129,7 +106,7 @@ __global__ void gn_partial_kernel(const char* x0, int c0, const char* x1, int c1
   }
   __syncthreads();
   const int cpg = C / GN_GROUPS;
-  for (int c = tid; c < C; c += nthr) {
+  for (int c = tid; c < C; c += blockDim.x) {
     const int gg = c / cpg;
     const float sc = s_rstd[gg] * gamma[c];
     const float sh = beta[c] - s_mean[gg] * sc;
@@ -229,9 +206,9 @@ extern "C" size_t tt_groupnorm_ws_bytes(int32_t nimg, int32_t hw, int32_t c) {
 
 extern "C" int tt_groupnorm_stats(const void* x0, int32_t c0, const void* x1, int32_t c1, int32_t nimg, int32_t hw,
                                   int32_t fpg, const float* gamma, const float* beta, float eps, float* scale, float* shift,
-                                  void* ws, size_t ws_bytes, uint32_t* counters, int32_t dtype, tt_stream_t stream) {
+                                  void* ws, size_t ws_bytes, int32_t dtype, tt_stream_t stream) {
   const int C = c0 + c1;
-  if (!x0 || !gamma || !beta || !scale || !shift || !ws || !counters) TT_FAIL(TT_EINVAL, "tt_groupnorm_stats: null operand");
+  if (!x0 || !gamma || !beta || !scale || !shift || !ws) TT_FAIL(TT_EINVAL, "tt_groupnorm_stats: null operand");
   if (c1 && !x1) TT_FAIL(TT_EINVAL, "tt_groupnorm_stats: c1 without x1");
   if (nimg <= 0 || hw <= 0 || C <= 0 || (C % GN_GROUPS) || (c0 & 7) || (c1 & 7)) TT_FAIL(TT_EINVAL, "tt_groupnorm_stats: C=%d+%d must be a multiple of 32, sources of 8", c0, c1);
   if (fpg <= 0 || nimg % fpg) TT_FAIL(TT_EINVAL, "tt_groupnorm_stats: frames_per_group %d does not divide %d images", fpg, nimg);
@@ -245,18 +222,14 @@ extern "C" int tt_groupnorm_stats(const void* x0, int32_t c0, const void* x1, in
   int threads = cv * rpb; if (threads < GN_GROUPS) threads = GN_GROUPS;
   threads = (threads + 63) / 64 * 64;
   hipStream_t st = (hipStream_t)stream;
-  if (nimg / fpg > TT_GN_MAX_GROUPS) TT_FAIL(TT_EUNSUPPORTED, "tt_groupnorm_stats: %d statistics groups (max %d)", nimg / fpg, TT_GN_MAX_GROUPS);
-  // dynamic LDS: per-channel scratch of the partial pass, re-used by the finalising block (slices x 32 doubles x 2 + 64
-  // floats), plus the "I am last" flag behind it (all LDS in the one dynamic array, 16-byte aligned: guide G17)
-  size_t lds = (size_t)2 * rpb * C * sizeof(float);
-  const size_t fin = (size_t)(threads / GN_GROUPS) * GN_GROUPS * 2 * sizeof(double) + 2 * GN_GROUPS * sizeof(float);
-  if (lds < fin) lds = fin;
-  lds = (lds + 15) / 16 * 16;
-  const int flag_off = (int)lds;
-  lds += 16;
-#define TT_GNP(TAG) hipLaunchKernelGGL(gn_partial_kernel<TAG>, dim3(chunks, nimg), dim3(threads), lds, st, (const char*)x0, c0, (const char*)x1, c1, hw, chunks, (double*)ws, fpg, gamma, beta, eps, scale, shift, (unsigned*)counters, flag_off)
-  if (dtype == TT_BF16) TT_GNP(bf16_tag); else if (dtype == TT_F16) TT_GNP(f16_tag); else TT_GNP(f32_tag);
-#undef TT_GNP
+  const size_t lds = (size_t)2 * rpb * C * sizeof(float);
+  if (dtype == TT_BF16)
+    hipLaunchKernelGGL(gn_partial_kernel<bf16_tag>, dim3(chunks, nimg), dim3(threads), lds, st, (const char*)x0, c0, (const char*)x1, c1, hw, chunks, (double*)ws);
+  else if (dtype == TT_F16)
+    hipLaunchKernelGGL(gn_partial_kernel<f16_tag>, dim3(chunks, nimg), dim3(threads), lds, st, (const char*)x0, c0, (const char*)x1, c1, hw, chunks, (double*)ws);
+  else
+    hipLaunchKernelGGL(gn_partial_kernel<f32_tag>, dim3(chunks, nimg), dim3(threads), lds, st, (const char*)x0, c0, (const char*)x1, c1, hw, chunks, (double*)ws);
+  hipLaunchKernelGGL(gn_finalize_kernel, dim3(nimg / fpg), dim3(32 * GN_SLICES), 0, st, (const double*)ws, chunks, hw, C, fpg, gamma, beta, eps, scale, shift);
   TT_CHECK_LAUNCH("tt_groupnorm_stats");
   return TT_OK;
 }

@@ -172,20 +172,6 @@ def temporal_attention(qkv, out, *, batch, frames, hw, heads, head_dim):
     return out
 
 
-_GN_COUNTERS = {}
-GN_MAX_GROUPS = 1024          # TT_GN_MAX_GROUPS in include/ttvdm.h
-
-
-def _gn_counters(device) -> torch.Tensor:
-    """Arrival counters of tt_groupnorm_stats: zero-initialised once per (device, stream); every call leaves them zero.
-    Never re-allocated (a captured hipGraph keeps the address)."""
-    key = (device, torch.cuda.current_stream().cuda_stream)
-    buf = _GN_COUNTERS.get(key)
-    if buf is None:
-        buf = _GN_COUNTERS[key] = torch.zeros(GN_MAX_GROUPS, dtype=torch.int32, device=device)
-    return buf
-
-
 def groupnorm_stats(x0, x1, nimg, hw, frames_per_group, gamma, beta, eps):
     """-> (scale, shift) fp32 [nimg, C] with y = x*scale + shift."""
     lib = _lib.load()
@@ -197,8 +183,7 @@ def groupnorm_stats(x0, x1, nimg, hw, frames_per_group, gamma, beta, eps):
     scale = torch.empty((nimg, c), dtype=torch.float32, device=x0.device)
     shift = torch.empty_like(scale)
     check(lib.tt_groupnorm_stats(_p(x0), c0, _p(x1), c1, nimg, hw, frames_per_group, _p(gamma), _p(beta), eps,
-                                 _p(scale), _p(shift), _p(ws), ws_bytes, _p(_gn_counters(x0.device)), _code(x0.dtype), _stream()),
-          "tt_groupnorm_stats")
+                                 _p(scale), _p(shift), _p(ws), ws_bytes, _code(x0.dtype), _stream()), "tt_groupnorm_stats")
     return scale, shift
 
 
