@@ -381,7 +381,7 @@ def test_errors_are_loud(ops):
         ops.gemm(torch.zeros(8, 16, dtype=torch.float16), torch.zeros(8, 16, dtype=torch.float16))
 
 
-@pytest.mark.parametrize("cfg", list(range(17)))
+@pytest.mark.parametrize("cfg", list(range(20)))
 def test_gemm_every_tile_configuration(ops, cfg):
     """each entry of the tile table in gemm.hip, forced, on a ragged linear and a 2-source conv (bf16)."""
     from this_and_that_vdm_amd import _lib

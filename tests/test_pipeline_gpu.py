@@ -128,3 +128,57 @@ def test_argument_errors(parts):
     with pytest.raises(ValueError, match="window"):
         pipe(image.cuda(), cond, p_cn, height=64, width=128, num_frames=4, guess_mode=False, control_guidance_start=0.8,
              control_guidance_end=0.2)
+
+
+@torch.no_grad()
+def test_hub_folder_round_trip_runs_like_inference_py(parts, tmp_path):
+    """test_code/inference.py:322-381,171-180 on a local hub folder: unet/ and controlnet/ through from_pretrained(subfolder=...),
+    the pipeline through from_pretrained(folder, vae=, image_encoder=, unet=) picking feature_extractor/ and scheduler/ up from
+    the folder.  The reloaded models must reproduce the in-memory models BIT FOR BIT (checkpoint I/O is lossless), also from
+    a sharded checkpoint."""
+    import json
+    import os
+    from safetensors.torch import save_file
+    from this_and_that_vdm_amd.svd import (ControlNetModel, StableVideoDiffusionControlNetPipeline,
+                                           UNetSpatioTemporalConditionModel)
+    p_unet, p_cn, _, _, vae, clip, txt = parts
+    root = str(tmp_path)
+    p_unet.save_pretrained(os.path.join(root, "unet"))
+    p_cn.save_pretrained(os.path.join(root, "controlnet"))
+    os.makedirs(os.path.join(root, "feature_extractor"))
+    os.makedirs(os.path.join(root, "scheduler"))
+    json.dump({"image_mean": [0.48145466, 0.4578275, 0.40821073], "image_std": [0.26862954, 0.26130258, 0.27577711]},
+              open(os.path.join(root, "feature_extractor", "preprocessor_config.json"), "w"))
+    json.dump({"_class_name": "EulerDiscreteScheduler", "beta_start": 0.00085, "beta_end": 0.012, "beta_schedule": "scaled_linear",
+               "num_train_timesteps": 1000, "prediction_type": "v_prediction", "interpolation_type": "linear",
+               "use_karras_sigmas": True, "sigma_min": 0.002, "sigma_max": 700.0, "timestep_spacing": "leading",
+               "timestep_type": "continuous", "steps_offset": 1}, open(os.path.join(root, "scheduler", "scheduler_config.json"), "w"))
+    # a sharded copy of the unet next to it
+    sd = {k: v.detach().cpu().contiguous() for k, v in p_unet.state_dict().items()}
+    shard_dir = os.path.join(root, "unet_sharded")
+    os.makedirs(shard_dir)
+    json.dump({k: (list(v) if isinstance(v, tuple) else v) for k, v in p_unet.config.items()}, open(os.path.join(shard_dir, "config.json"), "w"))
+    keys = sorted(sd)
+    parts_ = {"diffusion_pytorch_model-00001-of-00002.safetensors": keys[: len(keys) // 2],
+              "diffusion_pytorch_model-00002-of-00002.safetensors": keys[len(keys) // 2:]}
+    for name, ks in parts_.items():
+        save_file({k: sd[k] for k in ks}, os.path.join(shard_dir, name))
+    json.dump({"weight_map": {k: n for n, ks in parts_.items() for k in ks}},
+              open(os.path.join(shard_dir, "diffusion_pytorch_model.safetensors.index.json"), "w"))
+
+    unet2 = UNetSpatioTemporalConditionModel.from_pretrained(root, subfolder="unet", low_cpu_mem_usage=True).to("cuda", torch.float16)
+    unet3 = UNetSpatioTemporalConditionModel.from_pretrained(root, subfolder="unet_sharded", torch_dtype=torch.float16).to("cuda")
+    cn2 = ControlNetModel.from_pretrained(root, subfolder="controlnet", low_cpu_mem_usage=True).to("cuda", torch.float16)
+    image, cond, ids = _request()
+    lat0 = torch.randn(1, 4, 4, 8, 16, generator=torch.Generator().manual_seed(5))
+    call = dict(prompt=ids.cuda(), use_text=True, text_encoder=txt, height=64, width=128, num_frames=4, num_inference_steps=2, fps=7,
+                motion_bucket_id=200, noise_aug_strength=0.0, output_type="latent", guess_mode=False)
+    outs = []
+    for unet, cn in ((p_unet, p_cn), (unet2, cn2), (unet3, cn2)):
+        pipe = StableVideoDiffusionControlNetPipeline.from_pretrained(root, vae=vae, image_encoder=clip, unet=unet)
+        pipe.set_progress_bar_config(disable=True)
+        assert pipe.feature_extractor is not None and pipe.scheduler.config.sigma_max == 700.0
+        outs.append(pipe(image.cuda(), cond, cn, latents=lat0.clone(), **call).frames.clone())
+    assert torch.isfinite(outs[0]).all()
+    assert torch.equal(outs[0], outs[1]), "models reloaded from the folder must reproduce the in-memory models bit for bit"
+    assert torch.equal(outs[0], outs[2]), "... also from a sharded checkpoint"

@@ -9,6 +9,7 @@
 //   the same LDS-DMA + swizzle as the GEMM.  K tile rows are permuted on the READ side (pi below) so
 //   that accumulator register r of a lane is key 16*(lane>>5)+r: P needs no data movement at all.
 //   Online softmax in fp32 with exp2; masked keys get -inf, running max starts at -1e30 (no NaN).
+#include <type_traits>
 #include "common.h"
 
 namespace {
@@ -33,7 +34,7 @@ constexpr int KB = 64;    // keys per tile
 __device__ __forceinline__ float fast_exp2(float x) { return __builtin_amdgcn_exp2f(x); }
 
 template <typename Tag, int D, int MASK>
-__global__ __launch_bounds__(256) void attn_kernel(const AttnP p) {
+__global__ __launch_bounds__(256, (D == 64 && Elem<Tag>::ES == 2) ? 2 : 1) void attn_kernel(const AttnP p) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   typedef typename Elem<Tag>::quad_t quad_t;
   constexpr int ES = Elem<Tag>::ES, EPC = Elem<Tag>::EPC;   // bytes per element, elements per 16-byte chunk
@@ -133,31 +134,77 @@ __global__ __launch_bounds__(256) void attn_kernel(const AttnP p) {
   // K-tile row read by MFMA row i = l31 so that accumulator reg r <-> key 16*hi + r  (see header)
   const int pi = 16 * ((l31 >> 2) & 1) + (l31 & 3) + 4 * (l31 >> 3);
 
-  stage(0, 0);
-  for (int t = 0; t < ntiles; ++t) {
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __syncthreads();
-    if (t + 1 < ntiles) stage((t + 1) & 1, t + 1);
-    const char* sk = smem + (t & 1) * STAGE;
-    const char* sv = sk + K_BYTES;
+  // ---- LDS addresses of the fragments this lane reads from a K / V^T tile.  The swizzle XOR depends on the lane's row, so
+  // it cannot sit in the instruction's immediate; the stage (buffer parity) and the K/V split can -- the tile loop is
+  // unrolled by two.  For D = 64 all 16 addresses are computed ONCE (every read is `ds_read_b128 v, vaddr offset:imm`, zero
+  // address VALU in the loop); wider heads keep only the row bases and pay one XOR + add per read (register budget).
+  const unsigned lds_base = lds_addr(smem);
+  constexpr bool PRE = D == 64 && ES == 2;
+  unsigned kaddr[PRE ? 2 : 1][PRE ? DS : 1], vaddr[PRE ? DB : 1][PRE ? 2 * PH : 1];
+  if constexpr (PRE) {
+#pragma unroll
+    for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+      for (int ds = 0; ds < DS; ++ds) kaddr[kb][ds] = lds_base + tile_off<KCPR>(kb * 32 + pi, ds * 2 + hi);
+#pragma unroll
+    for (int db = 0; db < DB; ++db)
+#pragma unroll
+      for (int k = 0; k < 2 * PH; ++k) vaddr[db][k] = lds_base + tile_off<VCPR>(db * 32 + l31, (k / PH) * (32 / EPC) + hi * PH + k % PH);
+  }
+  auto k_addr = [&](int kb, int ds) -> unsigned {
+    if constexpr (PRE) return kaddr[kb][ds]; else return lds_base + tile_off<KCPR>(kb * 32 + pi, ds * 2 + hi);
+  };
+  auto v_addr = [&](int db, int k) -> unsigned {
+    if constexpr (PRE) return vaddr[db][k]; else return lds_base + tile_off<VCPR>(db * 32 + l31, (k / PH) * (32 / EPC) + hi * PH + k % PH);
+  };
 
+  // One 64-key tile.  Fragment reads are raw ds_reads (the compiler serialised visible ones: read -> wait -> MFMA, eight
+  // times per key block) in batches of four, two batches in flight, retired by counted lgkmcnt waits: a batch lands under
+  // the MFMAs of the one before it; the first two V^T batches are requested BEFORE the softmax and land under its VALU work.
+  // A batch holds the fragments of TWO accumulators (both 32-key blocks for QK^T, two 32-wide d blocks for PV), so the
+  // MFMAs of a batch alternate accumulators: a chain of four dependent 16-pass MFMAs would stall the issue for half its time.
+  constexpr int NBK = DS / 2;                          // K batches: batch i = chunks ds {2i, 2i+1} of key blocks {0, 1}
+  constexpr int NBV = (DB / 2) * PH;                   // V^T batches: batch i = reads k {2m, 2m+1} of d blocks {2g, 2g+1}
+  static_assert(DS % 2 == 0 && DB % 2 == 0, "fragment batches of four");
+  auto tile = [&](int t, auto buf_tag, auto mask_tag) {
+    constexpr int BUF = decltype(buf_tag)::value;
+    constexpr bool MASKED = decltype(mask_tag)::value;
+    constexpr int KOFF = BUF * STAGE, VOFF = BUF * STAGE + K_BYTES;
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");          // this wave's share of tile t has landed ...
+    __syncthreads();                                           // ... and everybody's; the other buffer is free
+    if (t + 1 < ntiles) stage(BUF ^ 1, t + 1);
+    raw_u32x4_t fa[4], fb[4];                                  // two fragment batches (K first, then V^T)
+    auto read_k = [&](int i, raw_u32x4_t (&f)[4]) {
+#pragma unroll
+      for (int j = 0; j < 4; ++j) f[j] = lds_read16_raw_off<KOFF>(k_addr(j & 1, 2 * i + (j >> 1)));
+    };
+    auto read_v = [&](int i, raw_u32x4_t (&f)[4]) {
+#pragma unroll
+      for (int j = 0; j < 4; ++j) f[j] = lds_read16_raw_off<VOFF>(v_addr(2 * (i / PH) + (j & 1), 2 * (i % PH) + (j >> 1)));
+    };
     f32x16_t s[2];
 #pragma unroll
-    for (int kb = 0; kb < 2; ++kb) {
+    for (int kb = 0; kb < 2; ++kb)
 #pragma unroll
       for (int r = 0; r < 16; ++r) s[kb][r] = 0.f;
-      const int row = kb * 32 + pi;
+    read_k(0, fa);
+    read_k(1, fb);
 #pragma unroll
-      for (int ds = 0; ds < DS; ++ds) {
-        const uint4 kf = lds_read16(sk, tile_off<KCPR>(row, ds * 2 + hi));
-        s[kb] = Cvt<Tag>::mfma32(kf, qf[ds], s[kb]);
-      }
+    for (int i = 0; i < NBK; ++i) {
+      if (i + 1 < NBK) lds_wait<4>(); else lds_wait<0>();
+      const raw_u32x4_t (&f)[4] = (i & 1) ? fb : fa;
+#pragma unroll
+      for (int j = 0; j < 4; ++j)
+        s[j & 1] = Cvt<Tag>::mfma32(make_uint4(f[j].x, f[j].y, f[j].z, f[j].w), qf[2 * i + (j >> 1)], s[j & 1]);
+      __builtin_amdgcn_sched_barrier(0);                       // the MFMAs read the batch before it is re-filled
+      if (i + 2 < NBK) { if (i & 1) read_k(i + 2, fb); else read_k(i + 2, fa); }
     }
+    read_v(0, fa);
+    if constexpr (NBV > 1) read_v(1, fb);
     // ---- mask + online softmax (lane: one query, keys j0 + kb*32 + hi*16 + r).  Raw scores stay unscaled: the
     // 1/sqrt(d)*log2(e) factor c is folded into the exponent, p = exp2(s*c - m*c), one FMA per score.
-    const int j0 = t * KB;
-    const bool need_mask = j0 + KB > p.lk;                      // uniform: interior tiles skip the compares
-    if (need_mask) {
+    if constexpr (MASKED) {
+      const int j0 = t * KB;
 #pragma unroll
       for (int kb = 0; kb < 2; ++kb)
 #pragma unroll
@@ -193,19 +240,34 @@ __global__ __launch_bounds__(256) void attn_kernel(const AttnP p) {
 #pragma unroll
         for (int r = 0; r < 16; ++r) o[i][r] *= alpha;
     }
-    // ---- O^T += Vt_tile * P^T : k-slot (hi, e) of step (kb,h) is key kb*32 + 16*hi + EPC*h + e
+    // ---- O^T += Vt_tile * P^T : k-slot (hi, e) of read k = kb*PH + h is key kb*32 + 16*hi + EPC*h + e
 #pragma unroll
-    for (int db = 0; db < DB; ++db) {
-      const int row = db * 32 + l31;
+    for (int i = 0; i < NBV; ++i) {
+      if (i + 1 < NBV) lds_wait<4>(); else lds_wait<0>();
+      const raw_u32x4_t (&f)[4] = (i & 1) ? fb : fa;
 #pragma unroll
-      for (int kb = 0; kb < 2; ++kb)
-#pragma unroll
-        for (int h = 0; h < PH; ++h) {
-          const int chunk = kb * (32 / EPC) + hi * PH + h;
-          const uint4 vf = lds_read16(sv, tile_off<VCPR>(row, chunk));
-          o[db] = Cvt<Tag>::mfma32(vf, pf[kb][h], o[db]);
-        }
+      for (int j = 0; j < 4; ++j) {
+        const int db = 2 * (i / PH) + (j & 1), k = 2 * (i % PH) + (j >> 1);
+        o[db] = Cvt<Tag>::mfma32(make_uint4(f[j].x, f[j].y, f[j].z, f[j].w), pf[k / PH][k % PH], o[db]);
+      }
+      __builtin_amdgcn_sched_barrier(0);
+      if (i + 2 < NBV) { if (i & 1) read_v(i + 2, fb); else read_v(i + 2, fa); }
     }
+  };
+
+  stage(0, 0);
+  const bool ragged = (p.lk % KB) != 0;                         // only the last tile can hold keys >= lk
+  const int full = ragged ? ntiles - 1 : ntiles;
+  int t = 0;
+  for (; t + 1 < full; t += 2) {
+    tile(t, std::integral_constant<int, 0>{}, std::false_type{});
+    tile(t + 1, std::integral_constant<int, 1>{}, std::false_type{});
+  }
+  if (t < full) {
+    tile(t, std::integral_constant<int, 0>{}, std::false_type{});
+    if (ragged) tile(t + 1, std::integral_constant<int, 1>{}, std::true_type{});
+  } else if (ragged) {
+    tile(t, std::integral_constant<int, 0>{}, std::true_type{});
   }
   // ---- finalize: lane holds query l31, d = db*32 + 8g + 4hi + {0..3}.  Stored directly an instruction would write 16
   // bytes to each of 32 rows; instead the wave's 32 x D outputs go through a private LDS strip (the K/V ring is free

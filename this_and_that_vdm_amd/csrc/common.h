@@ -186,6 +186,14 @@ __device__ __forceinline__ raw_u32x4_t lds_read16_raw(unsigned addr) {
   asm volatile("ds_read_b128 %0, %1" : "=v"(v) : "v"(addr));
   return v;
 }
+// same with a compile-time byte offset in the instruction's 16-bit offset field (no address arithmetic per read)
+template <int OFF> __device__ __forceinline__ raw_u32x4_t lds_read16_raw_off(unsigned addr) {
+  static_assert(OFF >= 0, "offset");
+  raw_u32x4_t v;
+  if constexpr (OFF < 65536) asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(v) : "v"(addr), "n"(OFF));
+  else asm volatile("ds_read_b128 %0, %1" : "=v"(v) : "v"(addr + (unsigned)OFF));     // beyond the 16-bit field (fp32, D = 128)
+  return v;
+}
 __device__ __forceinline__ raw_u32x2_t lds_read8_raw(unsigned addr) {
   raw_u32x2_t v;
   asm volatile("ds_read_b64 %0, %1" : "=v"(v) : "v"(addr));

@@ -47,6 +47,9 @@ constexpr TileCfg kCfgs[] = {        // keep in step with launch<Tag>() in gemm_
   {128, 128, 32, 5, 4, 2},   // 14: 8 waves, 80 KiB, prefetch distance 4 (x32) -> 2 blocks/CU
   {128, 128, 64, 3, 4, 2},   // 15: 8 waves, 96 KiB, prefetch distance 2 -> 1 block/CU
   {128, 128, 64, 4, 4, 2},   // 16: 8 waves, 128 KiB, prefetch distance 3 -> 1 block/CU
+  {256, 256, 32, 4, 2, 4},   // 17: 8 waves, wave tile 128x64, 128 KiB: three 32 KiB tiles in flight
+  {256, 128, 64, 2, 4, 2},   // 18: 8 waves, wave tile 64x64, 96 KiB, plain double buffer
+  {256, 128, 32, 5, 4, 2},   // 19: 8 waves, wave tile 64x64, 120 KiB: four 24 KiB tiles in flight
 };
 constexpr int kNumCfgs = sizeof(kCfgs) / sizeof(kCfgs[0]);
 
@@ -72,13 +75,17 @@ struct Plan { int cfg, splitk; };
 // `wide_ok`: the 256x128 tile pays for tall-and-wide problems (GEGLU projections, fused QKV) unless the epilogue reads
 // per-row tensors (residual / blend / row vector): its 128-VGPR budget has no room to preload them, so they would be read
 // between the stores (measured: 16 us epilogue instead of 3)
-Plan make_plan(int m, int n, long ktot, bool allow_split, bool wide_ok = true) {
+Plan make_plan(int m, int n, long ktot, bool allow_split, bool wide_ok = true, bool mode0 = false) {
   Plan pl{0, 1};
   const int f = forced_cfg();
   const long b128 = (long)ceil_div(m, 128) * ceil_div(n, 128);
   const long b12864 = (long)ceil_div(m, 128) * ceil_div(n, 64);
   if (f >= 0 && f < kNumCfgs) pl.cfg = f;
   else if (n % 160 == 0 && n % 128 != 0 && n <= 960 && m >= 2048) pl.cfg = 7;
+  // wide outputs (GEGLU / fused QKV projections, no per-row epilogue operands): 256x256 tiles halve the LDS-fill traffic
+  // per flop, which is what bounds the 128-wide tiles (measured cold, tools/gemm_cold.py: +6..25 % at N >= 1920; the
+  // M = 3136, N = 10240 GEGLU projection is the exception)
+  else if (wide_ok && mode0 && n >= 1920 && (m >= 8192 || (m >= 3072 && n <= 5120))) pl.cfg = 9;
   else if (m >= 8192 && n >= 1024 && wide_ok) pl.cfg = 3;
   else if (m < 2048 && n >= 2560 && n % 160 == 0) pl.cfg = 7;
   else if (b128 >= 384) pl.cfg = 11;                 // 128x128 with 8 waves (32x64 wave tiles): 16 waves per CU
@@ -133,16 +140,16 @@ bool sq320_ok(const TtGemmArgs* a) {
          (!a->blend || (a->blend == a->residual && a->ld_blend == a->ld_res));
 }
 // tile shapes whose fused-LayerNorm variants are built (launch<Tag>() in gemm_kernel.h): the ones the planner picks
-static bool ln_capable(int cfg) { return cfg == 1 || cfg == 2 || cfg == 3 || cfg == 7 || cfg == 11 || cfg == 16; }
+static bool ln_capable(int cfg) { return cfg == 1 || cfg == 2 || cfg == 3 || cfg == 7 || cfg == 9 || cfg == 11 || cfg == 16; }
 static Plan plan_for(const TtGemmArgs* a) {
   if (a->dtype == TT_F32) return Plan{plan_f32(a->m, a->n), 1};
   const int taps = a->mode == 1 ? 9 : (a->mode == 2 ? 3 : 1);
   const bool allow = !a->geglu && !a->ln_fold;       // a K slice would see only part of a LayerNorm row
-  Plan pl = make_plan(a->m, a->n, (long)taps * (a->k0 + a->k1), allow, !(a->residual || a->blend || a->rowvec));
+  Plan pl = make_plan(a->m, a->n, (long)taps * (a->k0 + a->k1), allow, !(a->residual || a->blend || a->rowvec), a->mode == 0);
   if (a->ln_fold && !ln_capable(pl.cfg)) {           // a forced tile shape without the fused variant: planner's own choice
     const int keep = g_forced_cfg;
     g_forced_cfg = -1;
-    pl = make_plan(a->m, a->n, (long)taps * (a->k0 + a->k1), false, !(a->residual || a->blend || a->rowvec));
+    pl = make_plan(a->m, a->n, (long)taps * (a->k0 + a->k1), false, !(a->residual || a->blend || a->rowvec), a->mode == 0);
     g_forced_cfg = keep;
   }
   return pl;

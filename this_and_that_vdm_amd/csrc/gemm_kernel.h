@@ -986,14 +986,17 @@ void launch(GemmP& p, int cfg, hipStream_t st) {          // cfg = index into kC
     case 6: launch_cfg<Tag, 256, 128, 64, 3, 4, 2>(p, st); break;
     case 7: launch_cfg<Tag, 128, 160, 64, 2, 4, 1, true>(p, st); break;
     case 8: launch_cfg<Tag, 128, 320, 32, 3, 4, 2>(p, st); break;
-    case 9: launch_cfg<Tag, 256, 256, 64, 2, 2, 4>(p, st); break;
+    case 9: launch_cfg<Tag, 256, 256, 64, 2, 2, 4, true>(p, st); break;
     case 10: launch_cfg<Tag, 128, 128, 64, 4, 2, 2>(p, st); break;
     case 11: launch_cfg<Tag, 128, 128, 64, 2, 4, 2, true>(p, st); break;
     case 12: launch_cfg<Tag, 256, 160, 32, 3, 8, 1>(p, st); break;
     case 13: launch_cfg<Tag, 256, 128, 32, 4, 4, 2>(p, st); break;
     case 14: launch_cfg<Tag, 128, 128, 32, 5, 4, 2>(p, st); break;
     case 15: launch_cfg<Tag, 128, 128, 64, 3, 4, 2>(p, st); break;
-    default: launch_cfg<Tag, 128, 128, 64, 4, 4, 2, true>(p, st); break;
+    case 16: launch_cfg<Tag, 128, 128, 64, 4, 4, 2, true>(p, st); break;
+    case 17: launch_cfg<Tag, 256, 256, 32, 4, 2, 4>(p, st); break;
+    case 18: launch_cfg<Tag, 256, 128, 64, 2, 4, 2>(p, st); break;
+    default: launch_cfg<Tag, 256, 128, 32, 5, 4, 2>(p, st); break;
   }
 }
 
