@@ -203,6 +203,8 @@ def main():
     ap.add_argument("--mode", choices=["vgl", "vl"], default="vgl")
     ap.add_argument("--res", choices=["lo", "hi"], default="lo")
     ap.add_argument("--dtype", choices=["bf16", "fp16"], default="bf16")
+    ap.add_argument("--attn", choices=["bf16", "fp8"], default="bf16",
+                    help="fp8: spatial self-attention on OCP e4m3 operands with fp8 MFMA (BASELINE config 5; 16-bit elsewhere)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-kernel-profile", action="store_true")
     ap.add_argument("--stub-cpu", action="store_true",
@@ -228,6 +230,9 @@ def main():
     dtype = torch.bfloat16 if a.dtype == "bf16" else torch.float16
 
     unet, cn, bcast_s = build_models(a.mode, dtype, device, rank, world)
+    for m in (unet, cn):
+        if m is not None:
+            m.attention_fp8 = a.attn == "fp8"
     loop, args = make_loop(unet, cn, a.res, device, seed=rank)
 
     def fence():
@@ -271,8 +276,8 @@ def main():
         ms = dt / a.steps * 1e3
         step_tflop = STEP_TFLOP[(a.mode, a.res)]
         out = {
-            "metric": "denoise-steps/sec (14-frame 256x448 VGL, 25 steps)" if (a.mode, a.res) == ("vgl", "lo")
-                      else f"denoise-steps/sec (14-frame {h * 8}x{w * 8} {a.mode.upper()}, 25 steps)",
+            "metric": "denoise-steps/sec (14-frame 256x448 VGL, 25 steps)" if (a.mode, a.res, a.attn) == ("vgl", "lo", "bf16")
+                      else f"denoise-steps/sec (14-frame {h * 8}x{w * 8} {a.mode.upper()}{', fp8 attention' if a.attn == 'fp8' else ''}, 25 steps)",
             "value": world * a.steps / dt, "unit": "denoise-steps/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
             "ms_per_step": ms, "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": a.dtype,
             "data": "synthetic (random-init weights of the real architecture, seeded inputs)",
@@ -281,7 +286,7 @@ def main():
                                    f"{CTX_TOKENS} context tokens, heads (5,10,20,20)",
                        "mode": a.mode, "latent": [FRAMES, 4, h, w], "requests_per_gpu": 1,
                        "parallelism": f"{world} independent request(s), one per GPU; RCCL weight broadcast at start-up only",
-                       "hipgraph": True, "finite_output": finite,
+                       "hipgraph": True, "finite_output": finite, "spatial_self_attention": a.attn,
                        "step_tflop_algorithmic": step_tflop,
                        "step_mfma_frac_of_peak": step_tflop / (ms * 1e-3) / PEAK_TFLOPS,
                        "weight_broadcast_s": bcast_s, **extras},

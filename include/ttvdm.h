@@ -89,6 +89,10 @@ typedef struct TtGemmArgs {
    * (weight * gamma), centred over k so that each weight row sums to zero (then x W^T == (x - mean) W^T), and beta
    * enters through `bias` (this_and_that_vdm_amd/packing.py:fold_layernorm). */
   int32_t ln_fold; float ln_eps;
+  /* out_fp8 != 0: `out` receives OCP e4m3 bytes (row stride ldo BYTES, saturating conversion) instead of 16-bit values:
+   * the Q | K and V^T operands of tt_attention's fp8 path (BASELINE config 5).  Plain mode-0 linears only (ln_fold and
+   * out_col_hw are allowed; no geglu / residual / blend / rowvec / out_f32); dtype stays the 16-bit type of a0 / w. */
+  int32_t out_fp8;
 } TtGemmArgs;
 int tt_gemm(const TtGemmArgs* args, tt_stream_t stream);
 /* which tile configuration tt_gemm will use for this problem: cfg[0..6] = BM, BN, BK, ring stages, waves along M,
@@ -129,6 +133,12 @@ typedef struct TtAttnArgs {
   int32_t frames, ctx_batches;         /* masks 1,2 */
   int32_t dtype;
   int32_t batch0;                      /* masks 1,2: batch index of sequence 0 (a launch may cover a sub-range of the batch) */
+  /* fp8 != 0 (mask 0 only): q, k, vt hold OCP e4m3 bytes (strides in bytes = elements; written by tt_gemm out_fp8),
+   * QK^T and PV run on v_mfma_f32_32x32x16_fp8_fp8 with P = 256 * exp2(..) converted to e4m3 (the factor cancels against the
+   * row sum); softmax statistics and the output accumulation stay fp32, `out` is `dtype` (16-bit).  Scales are 1: the
+   * operands are LayerNorm-ed projections, far inside e4m3's +-448.  Its tolerance is e4m3's (3 mantissa bits), see
+   * tests/test_ops_gpu.py::test_attention_fp8. */
+  int32_t fp8;
 } TtAttnArgs;
 int tt_attention(const TtAttnArgs* args, tt_stream_t stream);
 

@@ -238,6 +238,8 @@ def test_captured_graphs_survive_scratch_growth_and_weight_reloads():
                     timesteps=sched.timesteps, controlnet_cond=inp["gesture_latents"] if with_cn else None)
 
     floor, ops.WS_FLOOR_BYTES = ops.WS_FLOOR_BYTES, 1 << 12        # tiny scratch floor: the larger request MUST outgrow it
+    ops._WS_RETIRED.extend(ops._WS.values())                       # start from no scratch at all (earlier tests left 64 MiB
+    ops._WS.clear()                                                # buffers; their graphs may live on, so retire, not free)
     try:
         retired0 = len(ops._WS_RETIRED)
         vl = DenoiseLoop(p_unet, None, use_graph=True)

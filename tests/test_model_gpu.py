@@ -40,3 +40,25 @@ def test_tiny_models_match_oracle_and_reference_vectors(name, dtype):
         print(f"{name} {dtype} {k}: {s}   [fraction of elements inside rtol 1e-3 / atol 1e-4: {s['frac_in_tol']:.4f}]")
     for k, s in stats.items():
         assert s["rel_l2"] <= rel and s["cos"] >= cos, (k, s)
+
+
+@pytest.mark.parametrize("dtype", [torch.float16, torch.bfloat16])
+def test_tiny_model_with_fp8_attention(dtype):
+    """BASELINE config 5's attention path switched on (``attention_fp8``): spatial self-attention on e4m3 operands, everything
+    else as before.  Tolerance stated: relative L2 <= 6e-2 against the fp32 oracle (e4m3 has 3 mantissa bits)."""
+    if not torch.cuda.is_available():
+        pytest.skip("needs a GPU")
+    from tests.parity_common import build_pair, err_stats, load_golden
+    g = load_golden("tiny_vgl")
+    p_unet, _, o_unet, _ = build_pair("tiny_vgl", dtype, "cuda:0", False)
+    t = float(g["timestep"])
+    x, ehs, ati = g["sample"], g["encoder_hidden_states"], g["added_time_ids"]
+    with torch.no_grad():
+        ref = o_unet(x, t, ehs, ati)
+        base = p_unet(x.cuda(), t, ehs.cuda(), ati.cuda(), return_dict=False)[0]
+        p_unet.attention_fp8 = True
+        got = p_unet(x.cuda(), t, ehs.cuda(), ati.cuda(), return_dict=False)[0]
+    s8, s16 = err_stats(got, ref), err_stats(base, ref)
+    print(f"tiny UNet {dtype}: fp8 attention {s8} | 16-bit attention {s16}")
+    assert not torch.equal(got, base), "the fp8 path must actually run"
+    assert s8["rel_l2"] <= 6e-2 and s8["cos"] >= 0.998, s8

@@ -154,6 +154,54 @@ def test_attention_self(ops, dtype, l, heads, d):
     close(out.view(nseq, l, c), _sdpa(q, k, v, heads), dtype)
 
 
+@pytest.mark.parametrize("dtype", DTYPES16)
+@pytest.mark.parametrize("l,heads,d", [(200, 2, 64), (1792, 1, 64), (448, 2, 64), (100, 1, 128)])
+def test_attention_fp8(ops, dtype, l, heads, d):
+    """BASELINE config 5: spatial self-attention on OCP e4m3 operands (v_mfma_f32_32x32x16_fp8_fp8), 16-bit output.
+    Checked against fp32 SDPA on the SAME e4m3 values (what the kernel adds on top: P rounded to e4m3, 3 mantissa bits,
+    inside fp32 sums) at rtol = atol = 3e-2, and -- printed -- against SDPA on the unquantised 16-bit values."""
+    nseq, c = 2, heads * d
+    q, k, v = (rnd(nseq, l, c, dtype=dtype, seed=s) for s in (1, 2, 3))
+    q8, k8, v8 = (t.to(ops.FP8) for t in (q, k, v))
+    lp = (l + 15) // 16 * 16
+    vt = torch.zeros(c, nseq * lp, dtype=torch.uint8).view(ops.FP8)
+    vt.view(torch.uint8).view(c, nseq, lp)[:, :, :l] = v8.view(torch.uint8).permute(2, 0, 1)
+    out = torch.empty(nseq * l, c, dtype=dtype, device="cuda")
+    ops.attention(q8.reshape(-1, c).cuda(), k8.reshape(-1, c).cuda(), vt.cuda(), out, nseq=nseq, lq=l, heads=heads, head_dim=d,
+                  mask=0, lk=l, k_seq_stride=l, v_seq_stride=lp)
+    ref8 = _sdpa(q8.float(), k8.float(), v8.float(), heads)
+    torch.testing.assert_close(out.view(nseq, l, c).float().cpu(), ref8, rtol=3e-2, atol=3e-2)
+    ref = _sdpa(q, k, v, heads)
+    err = (out.view(nseq, l, c).float().cpu() - ref)
+    print(f"fp8 attention L={l} d={d} {dtype}: vs SDPA on e4m3 inputs max {float((out.view(nseq, l, c).float().cpu() - ref8).abs().max()):.4f}; "
+          f"vs SDPA on 16-bit inputs max {float(err.abs().max()):.4f}, rel-L2 {float(err.norm() / ref.norm()):.4f}")
+    assert float(err.norm() / ref.norm()) <= 0.1
+
+
+@pytest.mark.parametrize("dtype", DTYPES16)
+def test_gemm_fp8_output(ops, dtype):
+    """tt_gemm out_fp8: e4m3 bytes of the Q | K projection (LayerNorm folded, bias) and of the transposed, padded V^T."""
+    from this_and_that_vdm_amd.packing import fold_layernorm, zero_sum_round
+    m, c, n = 500, 128, 256
+    x = (rnd(m, c, dtype=torch.float32, seed=1) + 0.3).to(dtype)
+    w, b = rnd(n, c, dtype=dtype, seed=2, scale=c ** -0.5), rnd(n, dtype=torch.float32, seed=3, scale=0.3)
+    g, be = rnd(c, dtype=torch.float32, seed=4, scale=0.2) + 1, rnd(c, dtype=torch.float32, seed=5, scale=0.3)
+    wf, bf = fold_layernorm(w.float(), b, g, be)
+    out = ops.gemm(x.cuda(), zero_sum_round(wf, dtype).cuda(), bias=bf.cuda(), ln_fold=1, ln_eps=1e-5, out_fp8=True)
+    assert out.dtype == ops.FP8 and out.shape == (m, n)
+    ref = F.linear(F.layer_norm(x.float(), (c,), g, be, 1e-5), w.float(), b)
+    # e4m3: 3 mantissa bits -> half an ulp is 2^-4 relative; subnormal step 2^-9
+    torch.testing.assert_close(out.float().cpu(), ref, rtol=2 ** -4 * 1.1, atol=2 ** -9)
+    big = ops.gemm((x * 300).to(dtype).cuda(), (w * 50).to(dtype).cuda(), out_fp8=True)          # saturates at +-448, never NaN
+    assert torch.isfinite(big.float()).all() and float(big.float().abs().max()) == 448.0
+    nseq, hw, hwp = 4, 125, 128
+    vt = torch.zeros(n, nseq * hwp, dtype=torch.uint8, device="cuda").view(ops.FP8)
+    ops.gemm(w.cuda(), x.cuda(), out=vt, out_col_pad=(hw, hwp), out_fp8=True)
+    got = vt.float().cpu().reshape(n, nseq, hwp)
+    torch.testing.assert_close(got[:, :, :hw], (w.float() @ x.float().T).reshape(n, nseq, hw), rtol=2 ** -4 * 1.1, atol=2 ** -9)
+    assert float(got[:, :, hw:].abs().max()) == 0.0
+
+
 @pytest.mark.parametrize("dtype", DTYPES)
 def test_attention_softmax_rescale_branch(ops, dtype):
     """one key in a LATER tile dominates a row: forces the online-softmax rescale (guide rule 26)."""

@@ -27,7 +27,7 @@ class TtGemmArgs(C.Structure):
         ("out", C.c_void_p), ("ldo", C.c_int64), ("out_f32", C.c_int32),
         ("out_col_hw", C.c_int32), ("out_col_hwp", C.c_int32), ("dtype", C.c_int32),
         ("ws", C.c_void_p), ("ws_bytes", C.c_int64),
-        ("ln_fold", C.c_int32), ("ln_eps", C.c_float),
+        ("ln_fold", C.c_int32), ("ln_eps", C.c_float), ("out_fp8", C.c_int32),
     ]
 
 
@@ -37,7 +37,7 @@ class TtAttnArgs(C.Structure):
         ("vt", C.c_void_p), ("ldvt", C.c_int64), ("out", C.c_void_p), ("ldo", C.c_int64),
         ("nseq", C.c_int32), ("lq", C.c_int32), ("heads", C.c_int32), ("head_dim", C.c_int32),
         ("mask", C.c_int32), ("lk", C.c_int32), ("k_seq_stride", C.c_int32), ("v_seq_stride", C.c_int32),
-        ("frames", C.c_int32), ("ctx_batches", C.c_int32), ("dtype", C.c_int32), ("batch0", C.c_int32),
+        ("frames", C.c_int32), ("ctx_batches", C.c_int32), ("dtype", C.c_int32), ("batch0", C.c_int32), ("fp8", C.c_int32),
     ]
 
 
@@ -94,7 +94,7 @@ def load():
     for name, (res, args) in SIGNATURES.items():
         fn = getattr(lib, name)          # AttributeError here == ABI mismatch with include/ttvdm.h
         fn.restype, fn.argtypes = res, args
-    if lib.tt_abi_version() != 2:
+    if lib.tt_abi_version() != 3:
         raise RuntimeError("libttvdm.so ABI version mismatch")
     _lib = lib
     return lib

@@ -297,6 +297,236 @@ __global__ __launch_bounds__(256, (D == 64 && Elem<Tag>::ES == 2) ? 2 : 1) void 
   }
 }
 
+// ---------------------------------------------------------------------------------------------
+// fp8 spatial self-attention (BASELINE config 5): Q, K, V^T arrive as OCP e4m3 bytes (tt_gemm out_fp8), both products run
+// on v_mfma_f32_32x32x16_fp8_fp8.  Same structure as attn_kernel (S^T = K Q^T, lane = one query, P already the "B" operand
+// of O^T += V^T P^T) with half the operand bytes: a 64-key tile is 4 KiB of K + 4 KiB of V^T (D = 64), a lane reads ONE
+// 16-byte chunk per two MFMAs (8 e4m3 each).  k-slot maps (any map works as long as both operands use it):
+//   QK^T   MFMA 2jj + h of a key block: lane half hi supplies d = 16 (2jj + hi) + 8h .. + 8   (chunk 2jj + hi of the row)
+//   PV     MFMA (kb, h): lane half hi supplies keys kb*32 + 16 hi + 8h .. + 8                 (chunk 2kb + hi of the V^T row)
+// P is exponentiated with +8 in the exponent (x256: e4m3's subnormal floor 2^-9 would flush every probability below
+// 0.002 of the row maximum; x256 moves the floor to 7.6e-6) -- the factor cancels against the row sum, which is taken
+// over the same scaled values.  Softmax statistics and both accumulations are fp32.
+typedef long fp8x8_t;
+template <typename Tag, int D>
+__global__ __launch_bounds__(256, 2) void attn8_kernel(const AttnP p) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  typedef typename Elem<Tag>::quad_t quad_t;
+  constexpr int ES = Elem<Tag>::ES;             // OUTPUT element size
+  constexpr int KCPR = D / 16, VCPR = KB / 16;  // 16-byte chunks per K row (D e4m3) / V^T row (64 keys)
+  constexpr int K_BYTES = KB * D, V_BYTES = D * KB, STAGE = K_BYTES + V_BYTES;
+  constexpr int KPT = (KB * KCPR) / 256, VPT = (D * VCPR) / 256;
+  constexpr int JJ = D / 32, DB = D / 32;       // chunk reads per K row per lane, 32-wide d blocks
+  static_assert(KPT >= 1 && VPT >= 1, "tile smaller than the block");
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int l31 = lane & 31, hi = lane >> 5;
+  const int head = blockIdx.y, seq = blockIdx.z, qblk = blockIdx.x;
+  const int kbase = seq * p.k_seq_stride, vbase = seq * p.v_seq_stride;
+  const int ntiles = (p.lk + KB - 1) / KB;
+  const int qrow = qblk * QB + wid * 32 + l31;
+  const bool qok = qrow < p.lq;
+  uint4 qf[JJ];
+  {
+    const char* qp = p.q + ((long)seq * p.lq + (qok ? qrow : 0)) * p.ldq + head * D;
+#pragma unroll
+    for (int jj = 0; jj < JJ; ++jj) qf[jj] = qok ? *(const uint4*)(qp + (2 * jj + hi) * 16) : make_uint4(0, 0, 0, 0);
+  }
+  constexpr int INV = (int)0x80000000;
+  const __amdgpu_buffer_rsrc_t rk = __builtin_amdgcn_make_buffer_rsrc((void*)p.k, 0, p.k_bytes, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rv = __builtin_amdgcn_make_buffer_rsrc((void*)p.vt, 0, p.vt_bytes, 0x00020000);
+  int kvo[KPT], kr[KPT], vvo[VPT], vc[VPT];
+#pragma unroll
+  for (int i = 0; i < KPT; ++i) {
+    const int slot = i * 256 + tid;
+    const int r = slot / KCPR, c = (slot % KCPR) ^ tile_swz<KCPR>(r);
+    kr[i] = r;
+    kvo[i] = (int)(((long)kbase + r) * p.ldk + head * D + c * 16);
+  }
+#pragma unroll
+  for (int i = 0; i < VPT; ++i) {
+    const int slot = i * 256 + tid;
+    const int r = slot / VCPR, c = (slot % VCPR) ^ tile_swz<VCPR>(r);
+    vc[i] = c * 16;
+    vvo[i] = (int)((long)(head * D + r) * p.ldvt + vbase + c * 16);
+  }
+  const int k_rows_left = p.k_rows_total - kbase;
+  const long v_cols_left = p.vt_cols_total - vbase;
+  auto stage = [&](int buf, int tile) {
+    const int j0 = tile * KB;
+    char* lk_ = smem + buf * STAGE + wid * 1024;
+    char* lv_ = smem + buf * STAGE + K_BYTES + wid * 1024;
+    const int soff_k = __builtin_amdgcn_readfirstlane((int)((long)j0 * p.ldk));
+    const int soff_v = j0;
+    const bool edge = j0 + KB > k_rows_left || j0 + KB > v_cols_left;
+#pragma unroll
+    for (int i = 0; i < KPT; ++i) {
+      int v = kvo[i];
+      if (edge && j0 + kr[i] >= k_rows_left) v = INV;
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(rk, (__attribute__((address_space(3))) void*)(lk_ + i * 4096), 16, v, soff_k, 0, 0);
+    }
+#pragma unroll
+    for (int i = 0; i < VPT; ++i) {
+      int v = vvo[i];
+      if (edge && j0 + vc[i] >= v_cols_left) v = INV;
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(rv, (__attribute__((address_space(3))) void*)(lv_ + i * 4096), 16, v, soff_v, 0, 0);
+    }
+  };
+  f32x16_t o[DB];
+#pragma unroll
+  for (int i = 0; i < DB; ++i)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) o[i][r] = 0.f;
+  float m_run = -1e30f, l_run = 0.f;
+  const int pi = 16 * ((l31 >> 2) & 1) + (l31 & 3) + 4 * (l31 >> 3);      // see attn_kernel: accumulator reg r <-> key 16 hi + r
+  const unsigned lds_base = lds_addr(smem);
+  unsigned kaddr[2][JJ], vaddr[DB][2];
+#pragma unroll
+  for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+    for (int jj = 0; jj < JJ; ++jj) kaddr[kb][jj] = lds_base + tile_off<KCPR>(kb * 32 + pi, 2 * jj + hi);
+#pragma unroll
+  for (int db = 0; db < DB; ++db)
+#pragma unroll
+    for (int kb = 0; kb < 2; ++kb) vaddr[db][kb] = lds_base + tile_off<VCPR>(db * 32 + l31, 2 * kb + hi);
+  auto mfma8 = [](unsigned a0, unsigned a1, unsigned b0, unsigned b1, f32x16_t c) {
+    return __builtin_amdgcn_mfma_f32_32x32x16_fp8_fp8((long)(((unsigned long)a1 << 32) | a0), (long)(((unsigned long)b1 << 32) | b0), c, 0, 0, 0);
+  };
+  auto tile = [&](int t, auto buf_tag, auto mask_tag) {
+    constexpr int BUF = decltype(buf_tag)::value;
+    constexpr bool MASKED = decltype(mask_tag)::value;
+    constexpr int KOFF = BUF * STAGE, VOFF = BUF * STAGE + K_BYTES;
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    if (t + 1 < ntiles) stage(BUF ^ 1, t + 1);
+    raw_u32x4_t kf[2][JJ], vf[DB][2];
+#pragma unroll
+    for (int jj = 0; jj < JJ; ++jj)
+#pragma unroll
+      for (int kb = 0; kb < 2; ++kb) kf[kb][jj] = lds_read16_raw_off<KOFF>(kaddr[kb][jj]);
+    f32x16_t s[2];
+#pragma unroll
+    for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) s[kb][r] = 0.f;
+    lds_wait<0>();
+#pragma unroll
+    for (int jj = 0; jj < JJ; ++jj)
+#pragma unroll
+      for (int h = 0; h < 2; ++h)
+#pragma unroll
+        for (int kb = 0; kb < 2; ++kb)           // alternate the two accumulators
+          s[kb] = h == 0 ? mfma8(kf[kb][jj].x, kf[kb][jj].y, qf[jj].x, qf[jj].y, s[kb])
+                         : mfma8(kf[kb][jj].z, kf[kb][jj].w, qf[jj].z, qf[jj].w, s[kb]);
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+      for (int db = 0; db < DB; ++db) vf[db][kb] = lds_read16_raw_off<VOFF>(vaddr[db][kb]);      // land under the softmax
+    if constexpr (MASKED) {
+      const int j0 = t * KB;
+#pragma unroll
+      for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int j = j0 + kb * 32 + hi * 16 + r;
+          if (j >= p.lk) s[kb][r] = -INFINITY;
+        }
+    }
+    float mx = s[0][0];
+#pragma unroll
+    for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) mx = fmaxf(mx, s[kb][r]);
+    mx = fmaxf(mx, __shfl_xor(mx, 32));
+    const float m_new = fmaxf(m_run, mx * p.scale_log2e);
+    const float alpha = fast_exp2(m_run - m_new);
+    m_run = m_new;
+    const float shift = 8.0f - m_new;                                      // P' = 256 * exp2(s c - m)
+    float psum = 0.f;
+    unsigned pf[2][2][2];                                                  // [kb][h][dword]: 8 e4m3 of keys kb*32 + 16 hi + 8h ..
+#pragma unroll
+    for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+      for (int h = 0; h < 2; ++h) {
+        float e[8];
+#pragma unroll
+        for (int r = 0; r < 8; ++r) { e[r] = fast_exp2(fmaf(s[kb][h * 8 + r], p.scale_log2e, shift)); psum += e[r]; }
+        int w0 = 0, w1 = 0;
+        w0 = __builtin_amdgcn_cvt_pk_fp8_f32(e[0], e[1], w0, false);
+        w0 = __builtin_amdgcn_cvt_pk_fp8_f32(e[2], e[3], w0, true);
+        w1 = __builtin_amdgcn_cvt_pk_fp8_f32(e[4], e[5], w1, false);
+        w1 = __builtin_amdgcn_cvt_pk_fp8_f32(e[6], e[7], w1, true);
+        pf[kb][h][0] = (unsigned)w0; pf[kb][h][1] = (unsigned)w1;
+      }
+    l_run = l_run * alpha + psum;
+    if (__any(alpha != 1.0f)) {
+#pragma unroll
+      for (int i = 0; i < DB; ++i)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) o[i][r] *= alpha;
+    }
+    lds_wait<0>();
+#pragma unroll
+    for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+      for (int h = 0; h < 2; ++h)
+#pragma unroll
+        for (int db = 0; db < DB; ++db)          // alternate the output accumulators
+          o[db] = h == 0 ? mfma8(vf[db][kb].x, vf[db][kb].y, pf[kb][0][0], pf[kb][0][1], o[db])
+                         : mfma8(vf[db][kb].z, vf[db][kb].w, pf[kb][1][0], pf[kb][1][1], o[db]);
+    __builtin_amdgcn_sched_barrier(0);
+  };
+  stage(0, 0);
+  const bool ragged = (p.lk % KB) != 0;
+  const int full = ragged ? ntiles - 1 : ntiles;
+  int t = 0;
+  for (; t + 1 < full; t += 2) {
+    tile(t, std::integral_constant<int, 0>{}, std::false_type{});
+    tile(t + 1, std::integral_constant<int, 1>{}, std::false_type{});
+  }
+  if (t < full) {
+    tile(t, std::integral_constant<int, 0>{}, std::false_type{});
+    if (ragged) tile(t + 1, std::integral_constant<int, 1>{}, std::true_type{});
+  } else if (ragged) {
+    tile(t, std::integral_constant<int, 0>{}, std::true_type{});
+  }
+  // ---- finalize (as attn_kernel): rows leave through a wave-private LDS strip as full D*ES-byte rows
+  float l_tot = l_run + __shfl_xor(l_run, 32);
+  const float inv = l_tot > 0.f ? 1.0f / l_tot : 0.f;
+  __syncthreads();
+  constexpr int ROWB_O = D * ES, CPR_O = ROWB_O / 16;
+  char* strip = smem + wid * (32 * ROWB_O);
+#pragma unroll
+  for (int db = 0; db < DB; ++db)
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+      const int byte = (db * 32 + 8 * g + 4 * hi) * ES;
+      const float v4[4] = {o[db][g * 4] * inv, o[db][g * 4 + 1] * inv, o[db][g * 4 + 2] * inv, o[db][g * 4 + 3] * inv};
+      *(quad_t*)(strip + l31 * ROWB_O + (((byte >> 4) ^ (l31 & (CPR_O - 1))) << 4) + (byte & 15)) = f32_to_quad<Tag>(v4);
+    }
+  constexpr int RPP = 64 / CPR_O;
+  const int oc = lane % CPR_O, orow = lane / CPR_O;
+#pragma unroll
+  for (int pass = 0; pass < 32 / RPP; ++pass) {
+    const int r = pass * RPP + orow;
+    const uint4 v = *(const uint4*)(strip + r * ROWB_O + ((oc ^ (r & (CPR_O - 1))) << 4));
+    const int qr = qblk * QB + wid * 32 + r;
+    if (qr < p.lq) *(uint4*)(p.out + (((long)seq * p.lq + qr) * p.ldo + head * D) * ES + oc * 16) = v;
+  }
+}
+
+template <typename Tag, int D>
+void launch_attn8(const AttnP& p, hipStream_t st) {
+  // the K/V ring (2 x 2 x 64 x D bytes) doubles as the 4 x 32 x D*ES-byte output strips
+  constexpr size_t ring = 2 * (KB * D + D * KB), strips = 4 * 32 * D * Elem<Tag>::ES;
+  constexpr size_t lds = ring > strips ? ring : strips;
+  static unsigned long long attr_done = 0;
+  tt_lds_opt_in((const void*)attn8_kernel<Tag, D>, (int)lds, &attr_done);
+  const dim3 grid((p.lq + QB - 1) / QB, p.heads, p.nseq);
+  hipLaunchKernelGGL((attn8_kernel<Tag, D>), grid, dim3(256), lds, st, p);
+}
+
 template <typename Tag, int D, int MASK>
 void launch_attn_m(const AttnP& p, hipStream_t st) {
   constexpr size_t lds = 2 * (KB * D * Elem<Tag>::ES + D * KB * Elem<Tag>::ES);
@@ -460,8 +690,10 @@ extern "C" int tt_attention(const TtAttnArgs* a, tt_stream_t stream) {
   if (a->lk > a->k_seq_stride || a->lk > a->v_seq_stride) TT_FAIL(TT_EINVAL, "tt_attention: lk exceeds sequence stride");
   if (a->mask == 2 && a->k_seq_stride != a->v_seq_stride) TT_FAIL(TT_EINVAL, "tt_attention: mask 2 needs equal k/v context strides");
   if (a->dtype != TT_BF16 && a->dtype != TT_F16 && a->dtype != TT_F32) TT_FAIL(TT_EINVAL, "tt_attention: bad dtype");
-  const int es = a->dtype == TT_F32 ? 4 : 2;
-  if (((a->ldq * es) & 15) || ((a->ldk * es) & 15) || ((a->ldvt * es) & 15) || ((a->ldo * es) & 15) || ((a->v_seq_stride * es) & 15))
+  if (a->fp8 && (a->mask != 0 || a->dtype == TT_F32)) TT_FAIL(TT_EUNSUPPORTED, "tt_attention: the fp8 path serves spatial self-attention (mask 0) with 16-bit output");
+  const int es = a->fp8 ? 1 : (a->dtype == TT_F32 ? 4 : 2);      // bytes per q/k/vt element
+  const int eso = a->dtype == TT_F32 ? 4 : 2;
+  if (((a->ldq * es) & 15) || ((a->ldk * es) & 15) || ((a->ldvt * es) & 15) || ((a->ldo * eso) & 15) || ((a->v_seq_stride * es) & 15))
     TT_FAIL(TT_EINVAL, "tt_attention: strides must keep 16-byte chunks aligned");
   AttnP p;
   p.q = (const char*)a->q; p.ldq = a->ldq; p.k = (const char*)a->k; p.ldk = a->ldk;
@@ -480,6 +712,12 @@ extern "C" int tt_attention(const TtAttnArgs* a, tt_stream_t stream) {
   }
   p.scale_log2e = 1.4426950408889634f / sqrtf((float)a->head_dim);
   hipStream_t st = (hipStream_t)stream;
+  if (a->fp8) {
+    if (a->dtype == TT_BF16) { if (a->head_dim == 64) launch_attn8<bf16_tag, 64>(p, st); else launch_attn8<bf16_tag, 128>(p, st); }
+    else { if (a->head_dim == 64) launch_attn8<f16_tag, 64>(p, st); else launch_attn8<f16_tag, 128>(p, st); }
+    TT_CHECK_LAUNCH("tt_attention");
+    return TT_OK;
+  }
   if (a->dtype == TT_BF16) { if (a->head_dim == 64) launch_attn<bf16_tag, 64>(p, st); else launch_attn<bf16_tag, 128>(p, st); }
   else if (a->dtype == TT_F16) { if (a->head_dim == 64) launch_attn<f16_tag, 64>(p, st); else launch_attn<f16_tag, 128>(p, st); }
   else { if (a->head_dim == 64) launch_attn<f32_tag, 64>(p, st); else launch_attn<f32_tag, 128>(p, st); }

@@ -135,7 +135,7 @@ extern "C" int tt_gemm_set_streaming_square(int32_t on) {
 
 bool sq320_ok(const TtGemmArgs* a) {
   if (g_sq320 < 0) { const char* e = getenv("TT_GEMM_SQ320"); g_sq320 = e ? atoi(e) : 0; }
-  return g_sq320 && a->dtype != TT_F32 && !a->ln_fold && forced_cfg() < 0 && a->mode == 0 && a->k1 == 0 && a->k0 == SQ_K && a->n == SQ_N && a->m >= 4096 &&
+  return g_sq320 && a->dtype != TT_F32 && !a->ln_fold && !a->out_fp8 && forced_cfg() < 0 && a->mode == 0 && a->k1 == 0 && a->k0 == SQ_K && a->n == SQ_N && a->m >= 4096 &&
          !a->geglu && !a->rowvec && !a->out_f32 && !a->out_col_hw &&
          (!a->blend || (a->blend == a->residual && a->ld_blend == a->ld_res));
 }
@@ -144,7 +144,7 @@ static bool ln_capable(int cfg) { return cfg == 1 || cfg == 2 || cfg == 3 || cfg
 static Plan plan_for(const TtGemmArgs* a) {
   if (a->dtype == TT_F32) return Plan{plan_f32(a->m, a->n), 1};
   const int taps = a->mode == 1 ? 9 : (a->mode == 2 ? 3 : 1);
-  const bool allow = !a->geglu && !a->ln_fold;       // a K slice would see only part of a LayerNorm row
+  const bool allow = !a->geglu && !a->ln_fold && !a->out_fp8;       // a K slice would see only part of a LayerNorm row
   Plan pl = make_plan(a->m, a->n, (long)taps * (a->k0 + a->k1), allow, !(a->residual || a->blend || a->rowvec), a->mode == 0);
   if (a->ln_fold && !ln_capable(pl.cfg)) {           // a forced tile shape without the fused variant: planner's own choice
     const int keep = g_forced_cfg;
@@ -191,6 +191,8 @@ extern "C" int tt_gemm(const TtGemmArgs* a, tt_stream_t stream) {
   if (a->ln_fold && (a->mode != 0 || a->k1 != 0 || !(a->ln_eps > 0.f)))
     TT_FAIL(TT_EINVAL, "tt_gemm: ln_fold needs mode 0, one source spanning the whole LayerNorm row (k0 = C) and ln_eps > 0");
   if (a->ln_fold == 2 && a->geglu) TT_FAIL(TT_EINVAL, "tt_gemm: ln_fold 2 (columns) cannot be combined with geglu");
+  if (a->out_fp8 && (a->dtype == TT_F32 || a->mode != 0 || a->geglu || a->residual || a->blend || a->rowvec || a->out_f32 || (a->ldo & 3)))
+    TT_FAIL(TT_EINVAL, "tt_gemm: out_fp8 is for plain 16-bit linears (no geglu / residual / blend / rowvec / fp32 out), ldo %% 4 == 0");
   GemmP p;
   p.a0 = (const char*)a->a0; p.a1 = (const char*)a->a1; p.k0 = a->k0; p.k1 = a->k1;
   p.lda0 = a->lda0; p.lda1 = a->lda1; p.w = (const char*)a->w; p.ldw = a->ldw;
@@ -204,7 +206,7 @@ extern "C" int tt_gemm(const TtGemmArgs* a, tt_stream_t stream) {
   const int es = a->dtype == TT_F32 ? 4 : 2;         // bytes per stored element
   p.out = (char*)a->out; p.ldo = a->ldo; p.out_f32 = a->dtype == TT_F32 ? 0 : a->out_f32;   // TT_F32 stores fp32 anyway
   p.out_col_hw = a->out_col_hw; p.out_col_hwp = a->out_col_hwp;
-  p.ln_fold = a->ln_fold; p.ln_eps = a->ln_eps;
+  p.ln_fold = a->ln_fold; p.ln_eps = a->ln_eps; p.out_fp8 = a->out_fp8;
   if (p.mode == 1) {
     if (p.nimg <= 0 || p.hin <= 0 || p.win <= 0 || p.hout <= 0 || p.wout <= 0 || p.stride < 1)
       TT_FAIL(TT_EINVAL, "tt_gemm: conv geometry");
@@ -223,7 +225,7 @@ extern "C" int tt_gemm(const TtGemmArgs* a, tt_stream_t stream) {
     p.a0_bytes = (unsigned)a0b; p.a1_bytes = (unsigned)a1b; p.w_bytes = (unsigned)wb;
     // epilogue operands (bounds-checked descriptors; 0 bytes = absent -> loads return 0)
     const long n_out = p.geglu ? p.n / 2 : p.n;
-    const long outb = ((long)(p.m - 1) * p.ldo + (p.out_col_hw > 0 ? p.ldo : n_out)) * (p.out_f32 ? 4 : es);
+    const long outb = ((long)(p.m - 1) * p.ldo + (p.out_col_hw > 0 ? p.ldo : n_out)) * (p.out_f32 ? 4 : (p.out_fp8 ? 1 : es));
     const long resb = p.residual ? ((long)(p.m - 1) * p.ld_res + p.n) * es : 0;
     const long blb = p.blend ? ((long)(p.m - 1) * p.ld_blend + p.n) * es : 0;
     const long rvb = p.rowvec ? ((long)((p.m - 1) / p.rowvec_rows) * p.ld_rowvec + p.n) * 4 : 0;

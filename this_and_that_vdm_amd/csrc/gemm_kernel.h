@@ -29,7 +29,19 @@ struct GemmP {
   int splitk;                       // > 1: block (tile, s) reduces K slice s and writes an fp32 slab to ws
   float* ws;                        // [splitk][m][n] fp32 partial sums
   int ln_fold; float ln_eps;        // fused LayerNorm of the A rows (1) / W rows (2): see gemm_kernel, MODE 3 / 4
+  int out_fp8;                      // store e4m3 bytes (operands of the fp8 attention path) instead of 16-bit values
 };
+
+// 4 floats -> 4 OCP e4m3 bytes (saturating at +-448: e4m3fn has no infinity, an overflow would become NaN)
+__device__ __forceinline__ unsigned pack4_fp8(const float* v) {
+  int w = 0;
+  w = __builtin_amdgcn_cvt_pk_fp8_f32(__builtin_amdgcn_fmed3f(v[0], -448.f, 448.f), __builtin_amdgcn_fmed3f(v[1], -448.f, 448.f), w, false);
+  w = __builtin_amdgcn_cvt_pk_fp8_f32(__builtin_amdgcn_fmed3f(v[2], -448.f, 448.f), __builtin_amdgcn_fmed3f(v[3], -448.f, 448.f), w, true);
+  return (unsigned)w;
+}
+__device__ __forceinline__ void st32(__amdgpu_buffer_rsrc_t r, int off, unsigned a) {
+  __builtin_amdgcn_raw_buffer_store_b32(a, r, off, 0, 0);
+}
 
 // ---- running sum and sum of squares of one 16-byte MFMA operand chunk (fused LayerNorm statistics).  16-bit storage: two
 // packed dot products per dword (v_dot2_f32_*: x . (1,1) and x . x, accumulated in fp32) -- the operand stays packed.
@@ -141,7 +153,19 @@ __device__ __forceinline__ void epilogue_quad(const GemmP& p, int gm, int gn, fl
 #pragma unroll
     for (int e = 0; e < 4; ++e) v[e] = p.alpha * r4[e] + (1.0f - p.alpha) * v[e];
   }
-  if (p.out_f32) {
+  if (p.out_fp8) {
+    if (p.out_col_hw > 0) {
+      const unsigned w = pack4_fp8(v);
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        const int c = gn + e;
+        const long oc = (long)(c / p.out_col_hw) * p.out_col_hwp + (c % p.out_col_hw);
+        *(unsigned char*)(p.out + (long)gm * p.ldo + oc) = (unsigned char)(w >> (8 * e));
+      }
+    } else {
+      *(unsigned*)(p.out + (long)gm * p.ldo + gn) = pack4_fp8(v);
+    }
+  } else if (p.out_f32) {
     *(float4*)(p.out + ((long)gm * p.ldo + gn) * 4) = make_float4(v[0], v[1], v[2], v[3]);
   } else if (p.out_col_hw > 0) {
 #pragma unroll
@@ -569,8 +593,8 @@ void gemm_kernel(const GemmP p) {
       //          128-VGPR budget has no room for the preload -- the residual.  A load issued after a store waits for
       //          that store (in-order vmcnt), so each batch loads first and stores last; the planner keeps such
       //          epilogues off the 256-row tiles.
-      auto run = [&](auto film_tag, auto inpass_tag) {
-        constexpr bool FILM = decltype(film_tag)::value, INPASS = decltype(inpass_tag)::value;
+      auto run = [&](auto film_tag, auto inpass_tag, auto out8_tag) {
+        constexpr bool FILM = decltype(film_tag)::value, INPASS = decltype(inpass_tag)::value, OUT8 = decltype(out8_tag)::value;
         const __amdgpu_buffer_rsrc_t r_rv = make_rsrc(p.rowvec, (FILM || INPASS) ? p.rowvec_bytes : 0);
         const __amdgpu_buffer_rsrc_t r_bl = make_rsrc(p.blend, INPASS ? p.blend_bytes : 0);
         const __amdgpu_buffer_rsrc_t r_res = make_rsrc(p.residual, (INPASS && !EARLY_RES) ? p.res_bytes : 0);
@@ -653,7 +677,8 @@ void gemm_kernel(const GemmP p) {
                     quad_to_f32<Tag>(bq, b4v);
 #pragma unroll
                     for (int e = 0; e < 4; ++e) v[e] = alpha * b4v[e] + one_m_alpha * (v[e] + r4[e]);
-                    stq<Tag>(r_out, ok ? (int)(((long)gm * p.ldo + gn) * ES) : kInv, v);
+                    if constexpr (OUT8) st32(r_out, ok ? (int)((long)gm * p.ldo + gn) : kInv, pack4_fp8(v));
+                    else stq<Tag>(r_out, ok ? (int)(((long)gm * p.ldo + gn) * ES) : kInv, v);
                   }
                 }
               }
@@ -662,9 +687,11 @@ void gemm_kernel(const GemmP p) {
         }
       };
       const bool inpass = (p.blend && !blend_is_res) || (p.rowvec && p.rowvec_rows < 32) || (!EARLY_RES && p.residual);
-      if (inpass) run(std::false_type{}, std::true_type{});
-      else if (p.rowvec) run(std::true_type{}, std::false_type{});
-      else run(std::false_type{}, std::false_type{});
+      if (inpass) run(std::false_type{}, std::true_type{}, std::false_type{});
+      else if (p.rowvec) run(std::true_type{}, std::false_type{}, std::false_type{});
+      else if (MODE == 0 && ES == 2 && p.out_fp8) {          // Q | K and V^T of the fp8 attention path (linear, no residual)
+        if constexpr (MODE == 0 && ES == 2) run(std::false_type{}, std::false_type{}, std::true_type{});
+      } else run(std::false_type{}, std::false_type{}, std::false_type{});
     } else {
       // GEGLU: value/gate pairs are lane-local (regs g=0/2 value, g=1/3 gate); gelu in registers, then the 16
       // output columns of each fragment go through the strip: 2 fragments -> 32 output columns = 64 bytes per row.

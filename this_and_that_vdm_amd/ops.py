@@ -61,6 +61,7 @@ def _code(dt: torch.dtype) -> int:
 
 
 _TAG = {TT_BF16: "bf16_tag", TT_F16: "f16_tag", TT_F32: "f32_tag"}
+FP8 = torch.float8_e4m3fn          # OCP e4m3 (gfx950's fp8; not MI300's fnuz)
 
 
 def _stream():
@@ -84,10 +85,12 @@ def _rows2d(t: torch.Tensor) -> Tuple[int, int]:
 def gemm(a0: torch.Tensor, w: torch.Tensor, *, a1: Optional[torch.Tensor] = None, mode: int = 0, conv=None, tconv=None,
          bias=None, acc_scale: float = 1.0, rowvec=None, rowvec_rows: int = 0, geglu: bool = False, residual=None,
          blend=None, alpha: float = 0.0, out: Optional[torch.Tensor] = None, out_f32: bool = False, m: Optional[int] = None,
-         out_col_pad: Optional[Tuple[int, int]] = None, ln_fold: int = 0, ln_eps: float = 1e-5) -> torch.Tensor:
+         out_col_pad: Optional[Tuple[int, int]] = None, ln_fold: int = 0, ln_eps: float = 1e-5,
+         out_fp8: bool = False) -> torch.Tensor:
     """out[m, n] = epilogue(gather(a0|a1) @ w.T); see TtGemmArgs in include/ttvdm.h.
     conv = (nimg, hin, win, hout, wout, stride, upsample); tconv = (frames, hw).
-    ln_fold: 1 = rows of a0 / 2 = rows of w are LayerNorm inputs (weights pre-folded by packing.fold_layernorm)."""
+    ln_fold: 1 = rows of a0 / 2 = rows of w are LayerNorm inputs (weights pre-folded by packing.fold_layernorm).
+    out_fp8: the output is stored as OCP e4m3 (torch.float8_e4m3fn), the operand format of attention(..., fp8 path)."""
     lib = _lib.load()
     g = TtGemmArgs()
     lda0, k0 = _rows2d(a0)
@@ -118,8 +121,10 @@ def gemm(a0: torch.Tensor, w: torch.Tensor, *, a1: Optional[torch.Tensor] = None
         g.blend, g.ld_blend, g.alpha = _p(blend), blend.stride(0), alpha
     n_out = n // 2 if geglu else n
     if out is None:
-        out = torch.empty((g.m, n_out), dtype=torch.float32 if out_f32 else a0.dtype, device=a0.device)
-    g.out, g.ldo, g.out_f32 = _p(out), out.stride(0), int(out_f32)
+        out = torch.empty((g.m, n_out), dtype=FP8 if out_fp8 else (torch.float32 if out_f32 else a0.dtype), device=a0.device)
+    if out_fp8 and out.dtype != FP8:
+        raise RuntimeError("out_fp8 needs a torch.float8_e4m3fn output tensor")
+    g.out, g.ldo, g.out_f32, g.out_fp8 = _p(out), out.stride(0), int(out_f32), int(out_fp8)
     if out_col_pad is not None:
         g.out_col_hw, g.out_col_hwp = out_col_pad
     g.dtype = _code(a0.dtype)
@@ -154,14 +159,16 @@ def attention(q, k, vt, out, *, nseq, lq, heads, head_dim, mask, lk, k_seq_strid
     a.out, a.ldo = _p(out), out.stride(0)
     a.nseq, a.lq, a.heads, a.head_dim = nseq, lq, heads, head_dim
     a.mask, a.lk, a.k_seq_stride, a.v_seq_stride = mask, lk, k_seq_stride, v_seq_stride
-    a.frames, a.ctx_batches, a.dtype, a.batch0 = frames, ctx_batches, _code(q.dtype), batch0
+    fp8 = q.dtype == FP8                       # e4m3 operands (gemm(..., out_fp8=True)); the output type names the kernel
+    if fp8 and not (k.dtype == FP8 and vt.dtype == FP8):
+        raise RuntimeError("fp8 attention needs q, k and vt in torch.float8_e4m3fn")
+    a.frames, a.ctx_batches, a.dtype, a.batch0, a.fp8 = frames, ctx_batches, _code(out.dtype if fp8 else q.dtype), batch0, int(fp8)
     ev = _prof_begin()
     check(lib.tt_attention(C.byref(a), _stream()), "tt_attention")
     if ev is not None:
         tag = _TAG[a.dtype]
-        keys = lk * (ctx_batches if mask == 2 else 1)
-        _prof_end(ev, f"attn_kernel<{tag}, {head_dim}, {mask}>", 4.0 * nseq * heads * lq * lk * head_dim,
-                  shape=("attn", nseq * heads, lq, lk, mask, 0))
+        kname = f"attn8_kernel<{tag}, {head_dim}>" if fp8 else f"attn_kernel<{tag}, {head_dim}, {mask}>"
+        _prof_end(ev, kname, 4.0 * nseq * heads * lq * lk * head_dim, shape=("attn", nseq * heads, lq, lk, mask, 0))
     return out
 
 

@@ -62,7 +62,8 @@ class DenoiseLoop:
             self.controlnet.prepare()
         # a captured graph holds raw pointers into the models' packed weights: the pack generation of both models is part
         # of the key, so load_state_dict / .to() / in-place updates between requests drop the stale graphs
-        packs = (id(self.unet), self.unet._pack_gen) + ((id(self.controlnet), self.controlnet._pack_gen) if self.controlnet is not None else ())
+        packs = (id(self.unet), self.unet._pack_gen, bool(self.unet.attention_fp8)) + \
+                ((id(self.controlnet), self.controlnet._pack_gen, bool(self.controlnet.attention_fp8)) if self.controlnet is not None else ())
         key = (b, f, h, w, dtype, self.controlnet is not None, tuple(encoder_hidden_states.shape), len(timesteps),
                guidance_scale is not None, self.image_guidance_scale, packs)   # the image scale is baked into the graph
         if key != self._key:                    # new shapes or new weights: new static buffers, new graph

@@ -30,6 +30,10 @@ class DenoiserBase(ModelMixin):
     # None: the parameter dtype if it is 16-bit, else bf16.  torch.float32 selects the reference-precision mode (TT_F32:
     # the same launch sequence on fp32 storage with the exact-fp32 MFMA, ~1/16 of the bf16 rate) used by the parity tests.
     compute_dtype: Optional[torch.dtype] = None
+    # True: the spatial self-attention (the O(L^2) kernel) runs on OCP e4m3 operands with fp8 MFMA (BASELINE config 5:
+    # "fp8 MFMA attention path"); projections write e4m3 directly, softmax / accumulation stay fp32.  Lower precision than the
+    # default 16-bit path (3 mantissa bits on Q, K, V, P): tests/test_ops_gpu.py::test_attention_fp8 states the tolerance.
+    attention_fp8: bool = False
 
     # ---- packing
     _pack_gen = 0          # bumped by every (re)pack: consumers holding raw pointers to packed buffers (captured
@@ -103,7 +107,7 @@ class DenoiserBase(ModelMixin):
     def _step_context(self, emb: torch.Tensor, context) -> StepContext:
         film = ops.small_linear(emb, self._film_w, self._film_b, act_in=True)     # every ResBlock's FiLM row at once
         k_all, vt_all, s, sp = context
-        return StepContext(film, k_all, vt_all, s, sp)
+        return StepContext(film, k_all, vt_all, s, sp, attn_fp8=bool(self.attention_fp8))
 
     # ---- encoder walk shared by both models
     def _encode(self, x, g: Geom, ctx: StepContext):

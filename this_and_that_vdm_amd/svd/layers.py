@@ -55,20 +55,24 @@ class StepContext:
     """Per-forward state shared by all blocks: FiLM rows of every ResBlock (one batched GEMV) and the
     cross-attention K / V^T of every attention layer (two GEMMs per request, step-invariant)."""
 
-    def __init__(self, film: torch.Tensor, k_all: torch.Tensor, vt_all: torch.Tensor, s_ctx: int, s_pad: int):
+    def __init__(self, film: torch.Tensor, k_all: torch.Tensor, vt_all: torch.Tensor, s_ctx: int, s_pad: int,
+                 attn_fp8: bool = False):
         self.film, self.k_all, self.vt_all, self.s_ctx, self.s_pad = film, k_all, vt_all, s_ctx, s_pad
+        self.attn_fp8 = attn_fp8            # spatial self-attention on e4m3 operands (BASELINE config 5)
 
     _VT_CACHE: Dict[tuple, torch.Tensor] = {}
 
-    def vt_buffer(self, c: int, cols: int, like: torch.Tensor) -> torch.Tensor:
+    def vt_buffer(self, c: int, cols: int, like: torch.Tensor, dtype: Optional[torch.dtype] = None) -> torch.Tensor:
         """Scratch for the transposed V projection of self-attention.  Persistent per shape: padding columns
         (sequence length not a multiple of 8) are zeroed once and never written, and launches on one stream
         are ordered, so layers can share it."""
         # one scratch per (stream, shape): the fused loop runs GestureNet and UNet encoders on two streams
-        key = (like.device, like.dtype, c, cols, torch.cuda.current_stream().cuda_stream)
+        dtype = like.dtype if dtype is None else dtype
+        key = (like.device, dtype, c, cols, torch.cuda.current_stream().cuda_stream)
         buf = StepContext._VT_CACHE.get(key)
         if buf is None:
-            buf = StepContext._VT_CACHE[key] = torch.zeros((c, cols), dtype=like.dtype, device=like.device)
+            buf = StepContext._VT_CACHE[key] = torch.zeros((c, cols), dtype=torch.uint8 if dtype == ops.FP8 else dtype,
+                                                           device=like.device).view(dtype)
         return buf
 
 
@@ -341,10 +345,12 @@ def _self_attention(x, attn: Attention, wqk, bqk, wv, eps, g: Geom, ctx: StepCon
     """spatial self-attention over hw tokens per frame on the UN-normalised hidden states: norm1 is folded into the QK
     projection (rows) and into the swapped V^T projection (columns); flash kernel."""
     c = attn.inner_dim
-    qk = ops.gemm(x, wqk, bias=bqk, ln_fold=1, ln_eps=eps)                # [M, 2C]
-    hwp = (g.hw + 7) // 8 * 8
-    vt = ctx.vt_buffer(c, g.n * hwp, x)
-    ops.gemm(wv, x, out=vt, out_col_pad=(g.hw, hwp) if hwp != g.hw else None, ln_fold=2, ln_eps=eps)
+    fp8 = ctx.attn_fp8 and x.dtype != torch.float32
+    qk = ops.gemm(x, wqk, bias=bqk, ln_fold=1, ln_eps=eps, out_fp8=fp8)   # [M, 2C]  (e4m3 bytes on the fp8 path)
+    pad = 16 if fp8 else 8                                                # V^T sequences start on 16-byte chunks
+    hwp = (g.hw + pad - 1) // pad * pad
+    vt = ctx.vt_buffer(c, g.n * hwp, x, ops.FP8 if fp8 else None)
+    ops.gemm(wv, x, out=vt, out_col_pad=(g.hw, hwp) if hwp != g.hw else None, ln_fold=2, ln_eps=eps, out_fp8=fp8)
     x_norm = x
     out = torch.empty((g.m, c), dtype=x_norm.dtype, device=x_norm.device)
     return ops.attention(qk[:, :c], qk[:, c:], vt, out, nseq=g.n, lq=g.hw, heads=attn.heads, head_dim=attn.dim_head,
