@@ -169,11 +169,12 @@ def test_full_size_two_steps_match_oracle(full, dtype, rel, cos):
         assert s["rel_l2"] <= rel and s["cos"] >= cos, (k, s)
 
 
-@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("dtype,fp8", [(torch.float32, False), (torch.bfloat16, False), (torch.bfloat16, True)])
 @torch.no_grad()
-def test_l0_transformer_block_at_64x112_matches_oracle(dtype):
+def test_l0_transformer_block_at_64x112_matches_oracle(dtype, fp8):
     """BASELINE config 5's block: one L0 TransformerSpatioTemporalModel at 64x112 latents (7168 tokens per frame), 14 frames,
-    no CFG batch (B = 1), 78 context tokens.  Product block driven through the same packing / context path the models use."""
+    no CFG batch (B = 1), 78 context tokens.  Product block driven through the same packing / context path the models use.
+    ``fp8``: the spatial self-attention over the 7168 tokens on e4m3 operands (the config's "fp8 MFMA attention path")."""
     if not torch.cuda.is_available():
         pytest.skip("needs a GPU")
     from oracle import models as om
@@ -201,16 +202,16 @@ def test_l0_transformer_block_at_64x112_matches_oracle(dtype):
         pad[:s_ctx] = ehs[0].to(dtype)
         k_all = ops.gemm(pad, torch.cat(reg.k_w, 0).to(dtype).contiguous())
         vt_all = ops.gemm(torch.cat(reg.v_w, 0).to(dtype).contiguous(), pad)
-        ctx = StepContext(None, k_all, vt_all, s_ctx, sp)
+        ctx = StepContext(None, k_all, vt_all, s_ctx, sp, attn_fp8=fp8)
         tok = ops.nchw_to_tokens(x.cuda(), dtype)
         out = p(tok, Geom(1, f, h, w), ctx)
         got = ops.tokens_to_nchw(out, f, c, h, w, torch.float32 if dtype == torch.float32 else dtype)
         st = err_stats(got, ref)
-        print(f"L0 transformer block at 64x112, {dtype} vs fp32 oracle: {st}")
+        print(f"L0 transformer block at 64x112, {dtype}{' + fp8 attention' if fp8 else ''} vs fp32 oracle: {st}")
         if dtype == torch.float32:
             assert_north_star(got, ref, "L0 transformer block at 64x112 (TT_F32)")
-        else:
-            assert st["rel_l2"] <= 2e-2 and st["cos"] >= 0.9995, st
+        else:                                   # measured: bf16 2.2e-3; with e4m3 attention operands the limit is 3e-2
+            assert st["rel_l2"] <= (3e-2 if fp8 else 1e-2) and st["cos"] >= 0.999, st
     finally:
         torch.set_num_threads(threads)
 
