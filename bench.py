@@ -256,13 +256,19 @@ def main():
         agg = kernel_profile(loop, args)
         tot_flops = sum(v[1] for v in agg.values())
         name, (cnt, fl, sec) = max(agg.items(), key=lambda kv: kv[1][2])
-        traffic = None               # HBM bytes per launch of that kernel from the committed rocprofv3 PMC passes
-        tfile = os.path.join(REPO, "profiles", "r1_hbm_traffic.json")
+        # HBM-side bytes per launch of that kernel: rocprofv3 PMC passes (FETCH_SIZE doubled, + WRITE_SIZE; tools/pmc_traffic.py)
+        # cannot run inside this process, so the figure comes from the committed profile of the SAME kernel instance and is
+        # stamped with where it was measured; it is null (not a stale number) when the dominant kernel has no entry there.
+        traffic, traffic_src = None, None
+        tfile = os.path.join(REPO, "profiles", "r2_hbm_traffic.json")
         if os.path.exists(tfile):
-            traffic = json.load(open(tfile)).get(f"{a.mode}_{a.res}", {}).get(name)
+            doc = json.load(open(tfile))
+            traffic = doc.get(f"{a.mode}_{a.res}", {}).get(name.replace("ttg::", ""))
+            if traffic is not None:
+                traffic_src = f"profiles/r2_hbm_traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, measured at commit {doc.get('_measured_at_commit', '?')})"
         roofline = {"bound": "mfma", "kernel": name, "launches_per_step": cnt,
                     "achieved": fl / sec / 1e12, "peak": PEAK_TFLOPS, "unit": "TFLOP/s",
-                    "frac": fl / sec / 1e12 / PEAK_TFLOPS, "traffic": traffic,
+                    "frac": fl / sec / 1e12 / PEAK_TFLOPS, "traffic": traffic, "traffic_source": traffic_src,
                     "algorithmic_gflop_per_launch": fl / cnt / 1e9, "avg_launch_us": sec / cnt * 1e6}
         extras["mfma_kernels"] = {k: {"launches": v[0], "tflop": v[1] / 1e12, "ms": v[2] * 1e3,
                                       "tflops": v[1] / v[2] / 1e12} for k, v in sorted(agg.items(), key=lambda kv: -kv[1][2])}

@@ -15,7 +15,7 @@ def per_kernel(d, counter):
         for r in csv.DictReader(open(f)):
             if r["Counter_Name"] != counter:
                 continue
-            m = re.search(r"(gemm_kernel|attn_kernel|tattn_kernel|splitk_epilogue_kernel)<[^>]*>", r["Kernel_Name"])
+            m = re.search(r"(gemm_kernel|attn_kernel|attn8_kernel|tattn_kernel|splitk_epilogue_kernel)<[^>]*>", r["Kernel_Name"])
             if not m:
                 continue
             a = acc[m.group(0)]
@@ -39,6 +39,14 @@ def main():
                    "(2*FETCH_SIZE + WRITE_SIZE)*1024 bytes (gfx950 FETCH_SIZE reads half of a wide coalesced stream, "
                    "MI355X_MICROARCH.md section HBM; counts L2<->fabric requests, Infinity-Cache hits included)")
     doc[key] = traffic
+    commit = os.environ.get("TT_COMMIT", "")
+    if not commit:
+        try:
+            import subprocess
+            commit = subprocess.run(["git", "rev-parse", "--short", "HEAD"], capture_output=True, text=True).stdout.strip()
+        except Exception:
+            commit = ""
+    doc["_measured_at_commit"] = commit or "unknown (no .git on the GPU box: see the committing revision of this file)"
     json.dump(doc, open(out, "w"), indent=1)
     json.dump(raw, open(raw_out, "w"), indent=1)
     for k, v in traffic.items():
