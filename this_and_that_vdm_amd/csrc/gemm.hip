@@ -82,10 +82,9 @@ Plan make_plan(int m, int n, long ktot, bool allow_split, bool wide_ok = true, b
   const long b12864 = (long)ceil_div(m, 128) * ceil_div(n, 64);
   if (f >= 0 && f < kNumCfgs) pl.cfg = f;
   else if (n % 160 == 0 && n % 128 != 0 && n <= 960 && m >= 2048) pl.cfg = 7;
-  // wide outputs (GEGLU / fused QKV projections, no per-row epilogue operands): 256x256 tiles halve the LDS-fill traffic
-  // per flop, which is what bounds the 128-wide tiles (measured cold, tools/gemm_cold.py: +6..25 % at N >= 1920; the
-  // M = 3136, N = 10240 GEGLU projection is the exception)
-  else if (wide_ok && mode0 && n >= 1920 && (m >= 8192 || (m >= 3072 && n <= 5120))) pl.cfg = 9;
+  // (256x256 tiles -- cfg 9 -- win 6..25 % on the wide GEGLU / QKV projections in isolation (tools/gemm_cold.py) but lose
+  // inside the two-branch step graph, where one 128 KiB block per CU shuts the other branch's kernels out: FF1 at 32x56
+  // 144 vs 137 us, QKV at 16x28 60 vs 48 us per launch -- profiles/r2_*_kernel_by_grid.txt history.  Not routed.)
   else if (m >= 8192 && n >= 1024 && wide_ok) pl.cfg = 3;
   else if (m < 2048 && n >= 2560 && n % 160 == 0) pl.cfg = 7;
   else if (b128 >= 384) pl.cfg = 11;                 // 128x128 with 8 waves (32x64 wave tiles): 16 waves per CU
