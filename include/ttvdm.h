@@ -112,6 +112,32 @@ int tt_gemm_set_tile_override(int32_t cfg);
 int tt_gemm_set_streaming_square(int32_t on);
 
 /* ------------------------------------------------------------------------------------------------
+ * tt_conv3x3: Conv2d 3x3 / stride 1 / pad 1 with the GroupNorm (+SiLU) of its INPUT fused in -- the ResnetBlock2D convs
+ * (norm1 -> SiLU -> conv1 (+ time-embedding FiLM), norm2 -> SiLU -> conv2 (+ shortcut); reached from
+ * unet_3d_blocks.py:1891-2316) without a normalised copy of the activation and with the input staged in LDS as a spatial
+ * patch with halo, read 9 times (once per tap) from there:
+ *   out[p][n] = bias[n] + rowvec[p / rowvec_rows][n] + residual[p][n] + sum_{tap,c} act(x[p+tap][c]) W[n][(tap, c)]
+ *   act(v) = silu?(v * gn_scale[image][c] + gn_shift[image][c])     (gn_* = outputs of tt_groupnorm_stats; NULL: identity)
+ * Halo pixels outside the image contribute exact zeros (zero padding of the ACTIVATED tensor, as in the reference).
+ * x0 | x1: token-major sources (virtual channel concat, c0 and c1 multiples of 64); W as for tt_gemm mode 1.
+ * Serves the image sizes tt_conv3x3_supported() accepts (h x w tiled by 16x8, 8x16 or 8x14 rectangles); everything else
+ * (stride 2, upsampling, tiny images, TT_F32) stays on tt_groupnorm_apply + tt_gemm mode 1.
+ * ---------------------------------------------------------------------------------------------- */
+typedef struct TtConvArgs {
+  const void* x0; const void* x1; int32_t c0, c1; int64_t ld0, ld1;
+  const void* w; int64_t ldw;                 /* [n, 9*(c0+c1)], k index (tap, source, channel) */
+  int32_t nimg, h, w_img, n;
+  const float* gn_scale; const float* gn_shift; int32_t silu;     /* fp32 [nimg, c0+c1] each, or both NULL */
+  const float* bias;
+  const float* rowvec; int32_t rowvec_rows; int64_t ld_rowvec;
+  const void* residual; int64_t ld_res;
+  void* out; int64_t ldo;
+  int32_t dtype;                              /* TT_BF16 or TT_F16 */
+} TtConvArgs;
+int tt_conv3x3_supported(int32_t h, int32_t w, int32_t c0, int32_t c1, int32_t n, int32_t dtype);
+int tt_conv3x3(const TtConvArgs* args, tt_stream_t stream);
+
+/* ------------------------------------------------------------------------------------------------
  * tt_attention: softmax(Q K^T / sqrt(d)) V with online softmax on MFMA tiles; replaces
  * F.scaled_dot_product_attention inside diffusers AttnProcessor2_0 for
  *   mask 0  spatial self-attention            (BasicTransformerBlock.attn1; transformer_temporal.py:353)

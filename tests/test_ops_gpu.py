@@ -107,6 +107,40 @@ def test_gemm_conv3x3(ops, dtype, stride, upsample):
     close(out, ref.permute(0, 2, 3, 1).reshape(-1, cout), dtype)
 
 
+@pytest.mark.parametrize("dtype", DTYPES16)
+@pytest.mark.parametrize("h,w,c0,c1,cout", [(32, 56, 64, 0, 160), (16, 28, 128, 64, 128), (8, 16, 64, 64, 320), (8, 14, 192, 0, 64),
+                                            (64, 112, 64, 0, 96)])
+def test_conv3x3_fused_groupnorm(ops, dtype, h, w, c0, c1, cout):
+    """tt_conv3x3: conv3x3(silu(group_norm(cat(x0, x1)))) + bias + FiLM row + residual, GroupNorm applied while the input
+    patch (with halo) is staged in LDS; zero padding AFTER the activation; every tile shape (16x8, 8x14, 8x16)."""
+    nimg, frames = 4, 2
+    assert ops.conv3x3_supported(h, w, c0, c1, cout, dtype)
+    x0 = rnd(nimg, c0, h, w, dtype=dtype, seed=1, scale=2.0) + 0.5
+    x1 = rnd(nimg, c1, h, w, dtype=dtype, seed=2) if c1 else None
+    c = c0 + c1
+    wt = rnd(cout, c, 3, 3, dtype=dtype, seed=3, scale=(9 * c) ** -0.5)
+    bias = rnd(cout, dtype=torch.float32, seed=4)
+    gamma, beta = rnd(c, dtype=torch.float32, seed=5, scale=0.2) + 1, rnd(c, dtype=torch.float32, seed=6, scale=0.3)
+    film = rnd(nimg // frames, cout, dtype=torch.float32, seed=7)
+    res = rnd(nimg * h * w, cout, dtype=dtype, seed=8)
+    from this_and_that_vdm_amd.packing import pack_conv3x3
+    xin = torch.cat([x0, x1], 1).float() if c1 else x0.float()
+    act = F.silu(F.group_norm(xin, 32, gamma, beta, eps=1e-5))
+    ref = F.conv2d(act, wt.float(), bias, padding=1).permute(0, 2, 3, 1).reshape(-1, cout)
+    ref = ref + film.repeat_interleave(frames * h * w, 0) + res.float()
+    tok = lambda t: t.permute(0, 2, 3, 1).reshape(-1, t.shape[1]).contiguous().cuda()
+    t0, t1 = tok(x0), (tok(x1) if c1 else None)
+    st = ops.groupnorm_stats(t0, t1, nimg, h * w, 1, gamma.cuda(), beta.cuda(), 1e-5)
+    out = torch.full((nimg * h * w + 8, cout), 7.0, dtype=dtype, device="cuda")       # canary rows behind the output
+    ops.conv3x3(t0, t1, pack_conv3x3(wt).cuda(), nimg, h, w, gn=st, silu=True, bias=bias.cuda(), rowvec=film.cuda(),
+                rowvec_rows=frames * h * w, residual=res.cuda(), out=out[:nimg * h * w])
+    close(out[:nimg * h * w], ref, dtype, scale=2.0)
+    assert (out[nimg * h * w:] == 7.0).all()
+    # ... and without GroupNorm / epilogue terms (plain conv): equals the implicit-GEMM kernel's result up to rounding
+    plain = ops.conv3x3(t0, t1, pack_conv3x3(wt).cuda(), nimg, h, w)
+    close(plain, F.conv2d(xin, wt.float(), None, padding=1).permute(0, 2, 3, 1).reshape(-1, cout), dtype, scale=2.0)
+
+
 @pytest.mark.parametrize("dtype", DTYPES)
 def test_gemm_temporal_conv(ops, dtype):
     b, f, hw, c = 2, 5, 12, 64

@@ -41,6 +41,20 @@ class TtAttnArgs(C.Structure):
     ]
 
 
+class TtConvArgs(C.Structure):
+    _fields_ = [
+        ("x0", C.c_void_p), ("x1", C.c_void_p), ("c0", C.c_int32), ("c1", C.c_int32), ("ld0", C.c_int64), ("ld1", C.c_int64),
+        ("w", C.c_void_p), ("ldw", C.c_int64),
+        ("nimg", C.c_int32), ("h", C.c_int32), ("w_img", C.c_int32), ("n", C.c_int32),
+        ("gn_scale", C.c_void_p), ("gn_shift", C.c_void_p), ("silu", C.c_int32),
+        ("bias", C.c_void_p),
+        ("rowvec", C.c_void_p), ("rowvec_rows", C.c_int32), ("ld_rowvec", C.c_int64),
+        ("residual", C.c_void_p), ("ld_res", C.c_int64),
+        ("out", C.c_void_p), ("ldo", C.c_int64),
+        ("dtype", C.c_int32),
+    ]
+
+
 _i32, _i64, _f32, _vp, _sz = C.c_int32, C.c_int64, C.c_float, C.c_void_p, C.c_size_t
 
 # name -> (restype, argtypes): every symbol include/ttvdm.h declares
@@ -54,6 +68,8 @@ SIGNATURES = {
     "tt_gemm_set_tile_override": (C.c_int, [_i32]),
     "tt_gemm_ws_bytes": (_sz, [C.POINTER(TtGemmArgs)]),
     "tt_attention": (C.c_int, [C.POINTER(TtAttnArgs), _vp]),
+    "tt_conv3x3_supported": (C.c_int, [_i32, _i32, _i32, _i32, _i32, _i32]),
+    "tt_conv3x3": (C.c_int, [C.POINTER(TtConvArgs), _vp]),
     "tt_temporal_attention": (C.c_int, [_vp, _i64, _vp, _i64, _i32, _i32, _i32, _i32, _i32, _i32, _vp]),
     "tt_groupnorm_ws_bytes": (_sz, [_i32, _i32, _i32]),
     "tt_groupnorm_stats": (C.c_int, [_vp, _i32, _vp, _i32, _i32, _i32, _i32, _vp, _vp, _f32, _vp, _vp, _vp, _sz, _i32, _vp]),

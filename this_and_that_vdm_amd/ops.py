@@ -9,7 +9,7 @@ from typing import Optional, Tuple
 import torch
 
 from . import _lib
-from ._lib import TT_BF16, TT_F16, TT_F32, TtAttnArgs, TtGemmArgs, check
+from ._lib import TT_BF16, TT_F16, TT_F32, TtAttnArgs, TtConvArgs, TtGemmArgs, check
 
 
 # Optional launch profiler (bench.py): when set to a list, gemm()/attention() append
@@ -146,6 +146,43 @@ def gemm(a0: torch.Tensor, w: torch.Tensor, *, a1: Optional[torch.Tensor] = None
             kname = f"gemm_kernel<{tag}, {', '.join(str(v) for v in cfg[:6])}, {mode if not ln_fold else 2 + ln_fold}>"
         _prof_end(ev, kname, 2.0 * g.m * n * taps * (g.k0 + g.k1),
                   shape=(mode, g.m, n, taps * (g.k0 + g.k1), int(geglu), int(residual is not None)))
+    return out
+
+
+def conv3x3_supported(h: int, w: int, c0: int, c1: int, n: int, dtype: torch.dtype) -> bool:
+    """can tt_conv3x3 (fused GroupNorm + LDS-patch 3x3 conv) serve this problem?  Otherwise: groupnorm_apply + gemm(mode=1)."""
+    if dtype not in (torch.bfloat16, torch.float16):
+        return False
+    return bool(_lib.load().tt_conv3x3_supported(h, w, c0, c1, n, _code(dtype)))
+
+
+def conv3x3(x0, x1, w, nimg: int, h: int, wd: int, *, gn=None, silu: bool = True, bias=None, rowvec=None, rowvec_rows: int = 0,
+            residual=None, out=None):
+    """3x3 / stride 1 / pad 1 conv over token-major x0 | x1 with the input's GroupNorm (+SiLU) applied on the fly:
+    gn = (scale, shift) fp32 [nimg, C] from groupnorm_stats (None: raw input).  See TtConvArgs in include/ttvdm.h."""
+    lib = _lib.load()
+    a = TtConvArgs()
+    a.x0, a.c0, a.ld0 = _p(x0), x0.shape[1], x0.stride(0)
+    if x1 is not None:
+        a.x1, a.c1, a.ld1 = _p(x1), x1.shape[1], x1.stride(0)
+    n = w.shape[0]
+    a.w, a.ldw = _p(w), w.stride(0)
+    a.nimg, a.h, a.w_img, a.n = nimg, h, wd, n
+    if gn is not None:
+        a.gn_scale, a.gn_shift, a.silu = _p(gn[0]), _p(gn[1]), int(silu)
+    a.bias = _p(bias)
+    if rowvec is not None:
+        a.rowvec, a.rowvec_rows, a.ld_rowvec = _p(rowvec), rowvec_rows, rowvec.stride(0)
+    if residual is not None:
+        a.residual, a.ld_res = _p(residual), residual.stride(0)
+    if out is None:
+        out = torch.empty((nimg * h * wd, n), dtype=x0.dtype, device=x0.device)
+    a.out, a.ldo, a.dtype = _p(out), out.stride(0), _code(x0.dtype)
+    ev = _prof_begin()
+    check(lib.tt_conv3x3(C.byref(a), _stream()), "tt_conv3x3")
+    if ev is not None:
+        k = 9 * (a.c0 + a.c1)
+        _prof_end(ev, f"conv_patch_kernel<{_TAG[a.dtype]}>", 2.0 * nimg * h * wd * n * k, shape=(1, nimg * h * wd, n, k, 0, int(residual is not None)))
     return out
 
 

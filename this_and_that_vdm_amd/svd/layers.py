@@ -177,17 +177,30 @@ class ResnetBlock2D(_Packable):
 
     def forward(self, x0, x1, g: Geom, ctx: StepContext):
         off, c = self.film
+        film = g.film(ctx.film, off, c)
+        c0, c1 = x0.shape[1], (x1.shape[1] if x1 is not None else 0)
+        # tt_conv3x3: GroupNorm + SiLU applied while the input patch is staged in LDS (no normalised copy); image sizes /
+        # channel counts it does not tile (and TT_F32) take groupnorm_apply + the implicit-GEMM conv
+        fused = ops.conv3x3_supported(g.h, g.w, c0, c1, self.out_channels, x0.dtype) and \
+            ops.conv3x3_supported(g.h, g.w, self.out_channels, 0, self.out_channels, x0.dtype)
         conv = (g.n, g.h, g.w, g.h, g.w, 1, 0)
-        a = _gn(x0, x1, g, 1, self.g1, self.be1, self.eps, True)
-        hmid = ops.gemm(a, self.w1, mode=1, conv=conv, bias=self.b1, rowvec=g.film(ctx.film, off, c),
-                        rowvec_rows=g.frames * g.hw)
-        a = _gn(hmid, None, g, 1, self.g2, self.be2, self.eps, True)
+        st1 = ops.groupnorm_stats(x0, x1, g.n, g.hw, 1, self.g1, self.be1, self.eps)
+        if fused:
+            hmid = ops.conv3x3(x0, x1, self.w1, g.n, g.h, g.w, gn=st1, silu=True, bias=self.b1, rowvec=film,
+                               rowvec_rows=g.frames * g.hw)
+        else:
+            a = ops.groupnorm_apply(x0, x1, g.n, g.hw, st1[0], st1[1], True)
+            hmid = ops.gemm(a, self.w1, mode=1, conv=conv, bias=self.b1, rowvec=film, rowvec_rows=g.frames * g.hw)
+        st2 = ops.groupnorm_stats(hmid, None, g.n, g.hw, 1, self.g2, self.be2, self.eps)
         if self.conv_shortcut is not None:
             xs = ops.gemm(x0, self.ws, a1=x1, bias=self.bs)
         else:
             if x1 is not None:
                 raise RuntimeError("identity shortcut with a concatenated input")
             xs = x0
+        if fused:
+            return ops.conv3x3(hmid, None, self.w2, g.n, g.h, g.w, gn=st2, silu=True, bias=self.b2, residual=xs)
+        a = ops.groupnorm_apply(hmid, None, g.n, g.hw, st2[0], st2[1], True)
         return ops.gemm(a, self.w2, mode=1, conv=conv, bias=self.b2, residual=xs)
 
 
