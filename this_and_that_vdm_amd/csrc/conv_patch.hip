@@ -241,8 +241,9 @@ __global__ __launch_bounds__(256, 2) void conv_patch_kernel(const ConvP p) {
         const float4 t = *(const float4*)(ebuf + strip_off(r, qq, q_per_row));
         float r4[4];
         unpack4<Tag>(res[ps], r4);
-        const float v[4] = {t.x + b4.x + r4[0], t.y + b4.y + r4[1], t.z + b4.z + r4[2], t.w + b4.w + r4[3]};
-        st64(r_out, off[ps] >= 0 ? (int)(((long)off[ps] * p.ldo + gn) * 2) : kInv, pack2<Tag>(v[0], v[1]), pack2<Tag>(v[2], v[3]));
+        const float o0 = t.x + b4.x + r4[0], o1 = t.y + b4.y + r4[1], o2 = t.z + b4.z + r4[2], o3 = t.w + b4.w + r4[3];
+        const int ooff = off[ps] >= 0 ? (int)(((long)off[ps] * p.ldo + gn) * 2) : kInv;
+        st64(r_out, ooff, pack2<Tag>(o0, o1), pack2<Tag>(o2, o3));
       }
     }
   }
