@@ -134,8 +134,10 @@ __global__ __launch_bounds__(256, 2) void conv_patch_kernel(const ConvP p) {
     char* lds_w = smem + PATCH + (gt & 1) * WST + wid * 1024;
     const int soff = __builtin_amdgcn_readfirstlane((int)(((long)tap * ctot + (ch << 6)) * 2));
 #pragma unroll
-    for (int i = 0; i < BR; ++i)
-      __builtin_amdgcn_raw_ptr_buffer_load_lds(rw, (__attribute__((address_space(3))) void*)(lds_w + i * 4096), 16, vb[i], soff, 0, 0);
+    for (int i = 0; i < BR; ++i) {
+      const int v = vb[i];      // (hipcc: passing the captured array element itself makes the whole kernel template silently un-instantiable)
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(rw, (__attribute__((address_space(3))) void*)(lds_w + i * 4096), 16, v, soff, 0, 0);
+    }
   };
 
   // ---- fragment addresses
