@@ -62,3 +62,23 @@ def test_tiny_model_with_fp8_attention(dtype):
     print(f"tiny UNet {dtype}: fp8 attention {s8} | 16-bit attention {s16}")
     assert not torch.equal(got, base), "the fp8 path must actually run"
     assert s8["rel_l2"] <= 6e-2 and s8["cos"] >= 0.998, s8
+
+
+@pytest.mark.parametrize("dtype", [torch.float16, torch.bfloat16])
+def test_tiny_model_with_fused_groupnorm_convs(dtype, monkeypatch):
+    """The opt-in tt_conv3x3 route (TT_CONV3X3=1: ResBlock convs with GroupNorm + SiLU applied on the LDS patch) against the same
+    limits as the default route, and it must differ from it in bits (the normalised activations are rounded at another point)."""
+    if not torch.cuda.is_available():
+        pytest.skip("needs a GPU")
+    from this_and_that_vdm_amd import ops
+    base = run_tiny_vgl_parity(dtype, "cuda:0", "tiny_vgl")
+    monkeypatch.setattr(ops, "CONV3X3_FUSED", True)
+    calls = []
+    real = ops.conv3x3
+    monkeypatch.setattr(ops, "conv3x3", lambda *a, **k: (calls.append(1), real(*a, **k))[1])
+    stats = run_tiny_vgl_parity(dtype, "cuda:0", "tiny_vgl")
+    assert calls, "tt_conv3x3 was not used"
+    rel, cos = LIMITS[dtype]
+    for k, s in stats.items():
+        print(f"tiny_vgl {dtype} fused convs {k}: {s}   (default route: rel_l2 {base[k]['rel_l2']:.3e})")
+        assert s["rel_l2"] <= rel and s["cos"] >= cos, (k, s)

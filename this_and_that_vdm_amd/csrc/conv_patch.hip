@@ -41,6 +41,8 @@ struct ConvP {
 
 constexpr int CP_RS = 144;           // patch row stride: 64 channels x 2 B + 16 B (bank-conflict-free without swizzle)
 
+constexpr int CP_NST = 3;            // W ring depth: two (tap, chunk) tiles in flight behind the one being multiplied
+
 template <typename Tag, int TH, int TW, int BN>
 __global__ __launch_bounds__(256, 2) void conv_patch_kernel(const ConvP p) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -50,7 +52,7 @@ __global__ __launch_bounds__(256, 2) void conv_patch_kernel(const ConvP p) {
   constexpr int NPI = (PROWS + 31) / 32;                               // patch rows per thread
   constexpr int SLOTS = TH * TW;
   static_assert(SLOTS <= 128 && BN % 32 == 0 && (BN * 8) % 256 == 0, "tile shape");
-  static_assert(4 * 8192 <= PATCH + 2 * WST, "epilogue strips do not fit");
+  static_assert(4 * 8192 <= PATCH + CP_NST * WST, "epilogue strips do not fit");
 
   const int tid = threadIdx.x, lane = tid & 63;
   const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -129,13 +131,13 @@ __global__ __launch_bounds__(256, 2) void conv_patch_kernel(const ConvP p) {
     const int r = i * 32 + crow, gn = n0 + r;
     vb[i] = gn < p.n ? (int)(((long)gn * p.ldw + (cchunk ^ tile_swz<8>(r)) * 8) * 2) : kInv;
   }
-  auto stage_w = [&](int gt) {          // gt = chunk * 9 + tap
+  auto stage_w = [&](int gt, int slot, bool live) {          // gt = chunk * 9 + tap; !live: past the end, issued only to keep vmcnt uniform
     const int ch = gt / 9, tap = gt - ch * 9;
-    char* lds_w = smem + PATCH + (gt & 1) * WST + wid * 1024;
+    char* lds_w = smem + PATCH + slot * WST + wid * 1024;
     const int soff = __builtin_amdgcn_readfirstlane((int)(((long)tap * ctot + (ch << 6)) * 2));
 #pragma unroll
     for (int i = 0; i < BR; ++i) {
-      const int v = vb[i];      // (hipcc: passing the captured array element itself makes the whole kernel template silently un-instantiable)
+      const int v = live ? vb[i] : kInv;      // (hipcc: passing the captured array element itself makes the whole kernel template silently un-instantiable)
       __builtin_amdgcn_raw_ptr_buffer_load_lds(rw, (__attribute__((address_space(3))) void*)(lds_w + i * 4096), 16, v, soff, 0, 0);
     }
   };
@@ -154,22 +156,27 @@ __global__ __launch_bounds__(256, 2) void conv_patch_kernel(const ConvP p) {
 
   const int total = nchunks * 9;
   prefetch(0);
-  stage_w(0);
+  stage_w(0, 0, true);
+  stage_w(1, 1, total > 1);
+  int ring = 0;                                  // ring slot of tile gt
   for (int gt = 0; gt < total; ++gt) {
     const int ch = gt / 9, tap = gt - ch * 9;
+    // W tile gt has landed.  Younger VMEM traffic: tile gt + 1 (BR pieces) and, at taps 5 and 6, the patch prefetch issued at
+    // tap 4 (the prefetch of THIS chunk is older than tile gt at tap 0, so the same wait covers write_patch's operands).
+    if ((tap == 5 || tap == 6) && ch + 1 < nchunks) wait_vmcnt<BR + NPI>(); else wait_vmcnt<BR>();
     if (tap == 0) {
       __syncthreads();                          // every wave is done with the previous chunk's patch
       write_patch(ch);
     }
-    // W tile gt has landed (the patch prefetch issued during tap 4 is the only younger VMEM traffic, at tap 5)
-    if (tap == 5 && ch + 1 < nchunks) wait_vmcnt<NPI>(); else wait_vmcnt<0>();
-    __syncthreads();
+    __syncthreads();                            // tile gt visible to all waves; every wave is done with tile gt - 1
     asm volatile("" ::: "memory");
-    if (gt + 1 < total) stage_w(gt + 1);
+    const int free_slot = ring == 0 ? CP_NST - 1 : ring - 1;
+    stage_w(gt + 2, free_slot, gt + 2 < total);
     asm volatile("" ::: "memory");
     if (tap == 4 && ch + 1 < nchunks) prefetch(ch + 1);      // lands under taps 4 .. 8
     const unsigned a_tap = a_base + (unsigned)(((tap / 3) * PW + (tap % 3)) * CP_RS);
-    const unsigned w_tap = (unsigned)((gt & 1) * WST);
+    const unsigned w_tap = (unsigned)(ring * WST);
+    ring = ring == CP_NST - 1 ? 0 : ring + 1;
     raw_u32x4_t af[2], bf[2][FN];
     auto read = [&](int ks, raw_u32x4_t& a, raw_u32x4_t (&b)[FN]) {
       a = lds_read16_raw(a_tap + ks * 32);
@@ -254,8 +261,8 @@ __global__ __launch_bounds__(256, 2) void conv_patch_kernel(const ConvP p) {
 template <typename Tag, int TH, int TW, int BN>
 void launch_conv(const ConvP& p, hipStream_t st) {
   constexpr int PW = TW + 2, PROWS = (TH + 2) * PW;
-  constexpr size_t lds = (size_t)((PROWS * CP_RS + 1023) / 1024 * 1024) + 2 * (BN * 8 / 256) * 4096;
-  static_assert(2 * lds <= 160 * 1024, "two workgroups per CU");
+  constexpr size_t lds = (size_t)((PROWS * CP_RS + 1023) / 1024 * 1024) + CP_NST * (BN * 8 / 256) * 4096;
+  static_assert(lds <= 160 * 1024, "LDS");
   static unsigned long long attr_done = 0;
   tt_lds_opt_in((const void*)conv_patch_kernel<Tag, TH, TW, BN>, (int)lds, &attr_done);
   hipLaunchKernelGGL((conv_patch_kernel<Tag, TH, TW, BN>), dim3(p.nimg * p.tiles_y * p.tiles_x * p.tiles_n), dim3(256), lds, st, p);
@@ -308,7 +315,8 @@ extern "C" int tt_conv3x3(const TtConvArgs* a, tt_stream_t stream) {
     TT_FAIL(TT_EUNSUPPORTED, "tt_conv3x3: operand larger than 2 GiB (32-bit buffer offsets)");
   p.x0_bytes = (unsigned)x0b; p.x1_bytes = (unsigned)x1b; p.w_bytes = (unsigned)wb; p.out_bytes = (unsigned)outb;
   p.res_bytes = (unsigned)resb; p.bias_bytes = p.bias ? (unsigned)p.n * 4u : 0u; p.rowvec_bytes = (unsigned)rvb;
-  const int bn = (p.n % 160 == 0 && p.n % 128 != 0) ? 160 : 128;
+  int bn = (p.n % 160 == 0 && p.n % 128 != 0) ? 160 : 128;
+  if (const char* e = getenv("TT_CONV_BN")) bn = atoi(e) == 160 ? 160 : 128;      // tuning aid
   hipStream_t st = (hipStream_t)stream;
   const int tile = pick_tile(p.h, p.w_);
 #define TT_CV(TAG) do { if (tile == 1) launch_conv_bn<TAG, 16, 8>(p, bn, st); else if (tile == 2) launch_conv_bn<TAG, 8, 14>(p, bn, st); \

@@ -4,6 +4,7 @@ missing or the tensors are not on a HIP device."""
 from __future__ import annotations
 
 import ctypes as C
+import os
 from typing import Optional, Tuple
 
 import torch
@@ -147,6 +148,10 @@ def gemm(a0: torch.Tensor, w: torch.Tensor, *, a1: Optional[torch.Tensor] = None
         _prof_end(ev, kname, 2.0 * g.m * n * taps * (g.k0 + g.k1),
                   shape=(mode, g.m, n, taps * (g.k0 + g.k1), int(geglu), int(residual is not None)))
     return out
+
+
+# ResnetBlock2D routes its 3x3 convs through tt_conv3x3 only when asked to (measured slower than groupnorm_apply + tt_gemm mode 1)
+CONV3X3_FUSED = os.environ.get("TT_CONV3X3", "0") == "1"
 
 
 def conv3x3_supported(h: int, w: int, c0: int, c1: int, n: int, dtype: torch.dtype) -> bool:

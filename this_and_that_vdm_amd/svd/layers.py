@@ -179,9 +179,11 @@ class ResnetBlock2D(_Packable):
         off, c = self.film
         film = g.film(ctx.film, off, c)
         c0, c1 = x0.shape[1], (x1.shape[1] if x1 is not None else 0)
-        # tt_conv3x3: GroupNorm + SiLU applied while the input patch is staged in LDS (no normalised copy); image sizes /
-        # channel counts it does not tile (and TT_F32) take groupnorm_apply + the implicit-GEMM conv
-        fused = ops.conv3x3_supported(g.h, g.w, c0, c1, self.out_channels, x0.dtype) and \
+        # tt_conv3x3 (GroupNorm + SiLU applied while the input patch is staged in LDS, no normalised copy) is opt-in
+        # (TT_CONV3X3=1): every column tile re-does the SiLU of its patch, and at 5..10 column tiles per conv that costs more
+        # than the one tt_groupnorm_apply pass it removes (465-635 vs 770-950 TFLOP/s) -- the default is
+        # groupnorm_apply + the implicit-GEMM conv
+        fused = ops.CONV3X3_FUSED and ops.conv3x3_supported(g.h, g.w, c0, c1, self.out_channels, x0.dtype) and \
             ops.conv3x3_supported(g.h, g.w, self.out_channels, 0, self.out_channels, x0.dtype)
         conv = (g.n, g.h, g.w, g.h, g.w, 1, 0)
         st1 = ops.groupnorm_stats(x0, x1, g.n, g.hw, 1, self.g1, self.be1, self.eps)
