@@ -293,9 +293,13 @@ def test_temporal_self_attention(ops, dtype, frames, heads, d):
 
 
 @pytest.mark.parametrize("dtype", DTYPES)
-@pytest.mark.parametrize("c0,c1,fpg", [(64, 0, 1), (64, 32, 1), (320, 0, 4), (640, 320, 1)])
-def test_groupnorm(ops, dtype, c0, c1, fpg):
-    nimg, h, w = 4, 9, 11
+@pytest.mark.parametrize("c0,c1,fpg,h,w", [(64, 0, 1, 9, 11), (64, 32, 1, 9, 11), (320, 0, 4, 9, 11), (640, 320, 1, 9, 11),
+                                            (1280, 1280, 1, 8, 14), (640, 0, 1, 16, 28),      # one-kernel statistics (<= 640 KiB/image)
+                                            (320, 0, 1, 40, 56), (320, 320, 1, 32, 56)])      # partial + finalize kernels
+def test_groupnorm(ops, dtype, c0, c1, fpg, h, w):
+    """per-image statistics of small images run in one kernel (one block per image), larger ones and the cross-frame
+    statistics of the temporal ResBlocks (fpg > 1) in the partial + finalize pair"""
+    nimg = 4
     x0 = rnd(nimg, c0, h, w, dtype=dtype, seed=1, scale=3.0) + 1.5
     x1 = rnd(nimg, c1, h, w, dtype=dtype, seed=2) if c1 else None
     c = c0 + c1

@@ -117,6 +117,84 @@ __global__ __launch_bounds__(1024) void gn_finalize_kernel(const double* ws, int
   }
 }
 
+// Small images (at most GN_ONE_BYTES per image, per-image statistics): ONE kernel, one 1024-thread block per image -- the
+// partial + finalize pair costs two dependent launches (~5 us each in the step graph) for tensors a single CU streams in a
+// few microseconds.  Thread = (row lane, 8-channel vector); fp32 sums per thread over its rows (8 loads in flight), combined
+// per group in fp64 in a fixed order (bit-reproducible), then scale/shift for every channel of the image.
+constexpr long GN_ONE_BYTES = 640 * 1024;
+template <typename Tag>
+__global__ __launch_bounds__(1024) void gn_stats_image_kernel(const char* x0, int c0, const char* x1, int c1, int hw, int rpb,
+                                                              const float* gamma, const float* beta, float eps,
+                                                              float* scale, float* shift) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  __shared__ float s_mean[GN_GROUPS], s_rstd[GN_GROUPS];
+  const int C = c0 + c1, cv = C >> 3;
+  const int img = blockIdx.x, tid = threadIdx.x;
+  float* psum = (float*)smem;            // [rpb][C]
+  float* psq = psum + rpb * C;           // [rpb][C]
+  const int myv = tid % cv, myr = tid / cv;
+  if (myr < rpb) {
+    float s[8], q[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) s[e] = q[e] = 0.f;
+    const int ch = myv * 8;
+    const char* base; long ld; int coff;
+    if (ch < c0) { base = x0; ld = c0; coff = ch; } else { base = x1; ld = c1; coff = ch - c0; }
+    constexpr int ES = Elem<Tag>::ES;
+    const char* pbase = base + (((long)img * hw) * ld + coff) * ES;
+    const long rstride = ld * ES;
+    int r = myr;
+    for (; r + 7 * rpb < hw; r += 8 * rpb) {
+      float f[8][8];
+#pragma unroll
+      for (int k = 0; k < 8; ++k) load8<Tag>(pbase + (long)(r + k * rpb) * rstride, f[k]);
+#pragma unroll
+      for (int k = 0; k < 8; ++k) {
+#pragma unroll
+        for (int e = 0; e < 8; ++e) { s[e] += f[k][e]; q[e] = fmaf(f[k][e], f[k][e], q[e]); }
+      }
+    }
+    for (; r < hw; r += rpb) {
+      float f[8];
+      load8<Tag>(pbase + (long)r * rstride, f);
+#pragma unroll
+      for (int e = 0; e < 8; ++e) { s[e] += f[e]; q[e] = fmaf(f[e], f[e], q[e]); }
+    }
+#pragma unroll
+    for (int e = 0; e < 8; ++e) { psum[myr * C + ch + e] = s[e]; psq[myr * C + ch + e] = q[e]; }
+  }
+  __syncthreads();
+  const int cpg = C / GN_GROUPS;
+  {
+    // group g is summed by the 32 lanes tid = g*32 .. g*32+31 (slices of its rpb*cpg values), then combined by a wave-level
+    // fixed-order tree (xor shuffles: the same association on every run)
+    const int g = tid >> 5, sl = tid & 31;
+    double a = 0.0, b = 0.0;
+    const int n = rpb * cpg;
+    for (int i = sl; i < n; i += 32) {
+      const int r = i / cpg, c = g * cpg + (i - r * cpg);
+      a += (double)psum[r * C + c]; b += (double)psq[r * C + c];
+    }
+#pragma unroll
+    for (int o = 16; o > 0; o >>= 1) { a += __shfl_xor(a, o); b += __shfl_xor(b, o); }
+    if (sl == 0) {
+      const double cnt = (double)hw * cpg;
+      const double mean = a / cnt;
+      double var = b / cnt - mean * mean;
+      if (var < 0.0) var = 0.0;
+      s_mean[g] = (float)mean;
+      s_rstd[g] = (float)(1.0 / sqrt(var + (double)eps));
+    }
+  }
+  __syncthreads();
+  for (int c = tid; c < C; c += 1024) {
+    const int gg = c / cpg;
+    const float sc = s_rstd[gg] * gamma[c];
+    scale[(long)img * C + c] = sc;
+    shift[(long)img * C + c] = beta[c] - s_mean[gg] * sc;
+  }
+}
+
 template <typename Tag>
 __global__ void gn_apply_kernel(const char* x0, int c0, const char* x1, int c1, int hw, long total_vec,
                                 const float* scale, const float* shift, int silu, char* y, long ldy) {
@@ -222,6 +300,20 @@ extern "C" int tt_groupnorm_stats(const void* x0, int32_t c0, const void* x1, in
   int threads = cv * rpb; if (threads < GN_GROUPS) threads = GN_GROUPS;
   threads = (threads + 63) / 64 * 64;
   hipStream_t st = (hipStream_t)stream;
+  const int es = dtype == TT_F32 ? 4 : 2;
+  if (fpg == 1 && (long)hw * C * es <= GN_ONE_BYTES && cv <= 1024) {
+    int rpb1 = 1024 / cv;
+    while (rpb1 > 1 && (size_t)2 * rpb1 * C * sizeof(float) > 96 * 1024) --rpb1;     // [rpb][C] x 2 fp32 in LDS
+    if (rpb1 > hw) rpb1 = hw;
+    const size_t lds1 = (size_t)2 * rpb1 * C * sizeof(float);
+    static unsigned long long attr_done[3] = {0, 0, 0};
+#define TT_GN1(TAG, IDX) do { tt_lds_opt_in((const void*)gn_stats_image_kernel<TAG>, (int)lds1, &attr_done[IDX]); \
+      hipLaunchKernelGGL(gn_stats_image_kernel<TAG>, dim3(nimg), dim3(1024), lds1, st, (const char*)x0, c0, (const char*)x1, c1, hw, rpb1, gamma, beta, eps, scale, shift); } while (0)
+    if (dtype == TT_BF16) TT_GN1(bf16_tag, 0); else if (dtype == TT_F16) TT_GN1(f16_tag, 1); else TT_GN1(f32_tag, 2);
+#undef TT_GN1
+    TT_CHECK_LAUNCH("tt_groupnorm_stats");
+    return TT_OK;
+  }
   const size_t lds = (size_t)2 * rpb * C * sizeof(float);
   if (dtype == TT_BF16)
     hipLaunchKernelGGL(gn_partial_kernel<bf16_tag>, dim3(chunks, nimg), dim3(threads), lds, st, (const char*)x0, c0, (const char*)x1, c1, hw, chunks, (double*)ws);
