@@ -12,6 +12,11 @@ GOLDEN = os.path.join(REPO, "tests", "golden")
 
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run on the GPU box with -m gpu)")
+    # The oracle side of the parity tests is eager PyTorch-CPU.  On the GPU box's host (256 hardware threads) the default
+    # thread count is pathological for it (one UNet forward: 4.3 s at 32 threads, 275 s at 256 -- DESIGN.md section 6), and the
+    # tiny-model tests alone went from 45 s to 8 min on a busy host: cap it.
+    import torch
+    torch.set_num_threads(min(32, os.cpu_count() or 1))
 
 
 @pytest.fixture(scope="session")
