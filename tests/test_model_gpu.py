@@ -82,3 +82,57 @@ def test_tiny_model_with_fused_groupnorm_convs(dtype, monkeypatch):
     for k, s in stats.items():
         print(f"tiny_vgl {dtype} fused convs {k}: {s}   (default route: rel_l2 {base[k]['rel_l2']:.3e})")
         assert s["rel_l2"] <= rel and s["cos"] >= cos, (k, s)
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.float16])
+def test_zero_context_shortcut_and_general_path(dtype):
+    """Batch elements whose context is all zeros (the CFG uncond half of the golden inputs) skip the spatial cross-attention
+    arithmetic (exactly 0 + to_out's bias).  Checks: (a) the shortcut really drops work, (b) shortcut and general path agree
+    with each other and with the oracle, (c) a context without a zero half takes the general path and matches the oracle."""
+    if not torch.cuda.is_available():
+        pytest.skip("needs a GPU")
+    from tests.parity_common import assert_north_star, build_pair, err_stats, load_golden
+    from this_and_that_vdm_amd import ops
+    g = load_golden("tiny_vgl")
+    p_unet, _, o_unet, _ = build_pair("tiny_vgl", dtype, "cuda:0", False)
+    t = float(g["timestep"])
+    x, ehs, ati = g["sample"], g["encoder_hidden_states"], g["added_time_ids"]
+    assert not ehs[0].any() and ehs[1].any()
+    rows = []
+    real = ops.attention
+
+    def counting(q, *a, **k):
+        if k.get("mask") == 1:
+            rows.append(q.shape[0])
+        return real(q, *a, **k)
+
+    with torch.no_grad():
+        ref = o_unet(x, t, ehs, ati)
+        ops.attention = counting
+        try:
+            got_short = p_unet(x.cuda(), t, ehs.cuda(), ati.cuda(), return_dict=False)[0]
+            n_short, rows_short = len(rows), sum(rows)
+            rows.clear()
+            p_unet.zero_context_shortcut = False
+            got_full = p_unet(x.cuda(), t, ehs.cuda(), ati.cuda(), return_dict=False)[0]
+            n_full, rows_full = len(rows), sum(rows)
+            rows.clear()
+            p_unet.zero_context_shortcut = True
+            ehs2 = ehs.clone()
+            ehs2[0] = ehs[1].flip(0) * 0.5                      # no zero half: the general path must be taken
+            ref2 = o_unet(x, t, ehs2, ati)
+            got2 = p_unet(x.cuda(), t, ehs2.cuda(), ati.cuda(), return_dict=False)[0]
+            rows_nz = sum(rows)
+        finally:
+            ops.attention = real
+    assert n_short == n_full and 2 * rows_short == rows_full == rows_nz, (n_short, n_full, rows_short, rows_full, rows_nz)
+    s_short, s_full, s_2 = err_stats(got_short, ref), err_stats(got_full, ref), err_stats(got2, ref2)
+    print(f"{dtype}: shortcut {s_short} | general {s_full} | non-zero uncond context {s_2}")
+    if dtype == torch.float32:
+        assert_north_star(got_short, ref, "zero-context shortcut vs oracle")
+        assert_north_star(got_full, ref, "general path vs oracle")
+        assert_north_star(got2, ref2, "non-zero uncond context vs oracle")
+    else:
+        rel, cos = LIMITS[dtype]
+        for s in (s_short, s_full, s_2):
+            assert s["rel_l2"] <= rel and s["cos"] >= cos, s

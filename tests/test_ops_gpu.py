@@ -52,6 +52,22 @@ def test_gemm_linear_full_epilogue(ops, dtype, m, n, k):
 
 
 @pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("m,n,k", [(1000, 320, 320), (6272, 640, 640), (1568, 1280, 1280), (300, 128, 5120)])
+def test_gemm_in_place_on_the_residual(ops, dtype, m, n, k):
+    """out may alias the residual (the zero-context shortcut updates the live rows of the hidden states in place): every lane
+    reads the residual element it overwrites, in the tile kernels and in the split-K reduction alike -- bit-identical to the
+    out-of-place call, and rows outside the slice stay untouched."""
+    a, w = rnd(m, k, dtype=dtype, seed=1), rnd(n, k, dtype=dtype, seed=2, scale=k ** -0.5)
+    bias = rnd(n, dtype=torch.float32, seed=3)
+    x = rnd(m + 64, n, dtype=dtype, seed=5).cuda()
+    ref = ops.gemm(a.cuda(), w.cuda(), bias=bias.cuda(), residual=x[32:32 + m])
+    keep = x.clone()
+    ops.gemm(a.cuda(), w.cuda(), bias=bias.cuda(), residual=x[32:32 + m], out=x[32:32 + m])
+    assert torch.equal(x[32:32 + m], ref)
+    assert torch.equal(x[:32], keep[:32]) and torch.equal(x[32 + m:], keep[32 + m:])
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
 def test_gemm_is_transpose_safe(ops, dtype):
     """A = I with an asymmetric W: catches swapped row/col fragment maps (cdna guide rule 16)."""
     n = 96

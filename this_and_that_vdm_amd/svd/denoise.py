@@ -80,8 +80,11 @@ class DenoiseLoop:
         self.cur = self._static_set("cur", torch.zeros(3, dtype=torch.float32, device=dev))           # sigma, sigma_next, t
         self.num_steps = self.table.shape[0]
         ehs = encoder_hidden_states.to(dev)
-        k, vt, s, sp = self.unet.project_context(ehs)
-        self.ctx_unet = (self._static_set("k_unet", k), self._static_set("vt_unet", vt), s, sp)
+        k, vt, s, sp, zmask = self.unet.project_context(ehs)
+        if self._static.setdefault("zero_ctx_mask", zmask) != zmask:
+            self._graph = self._graph_off = None        # which rows skip cross-attention is part of the launch structure
+            self._static["zero_ctx_mask"] = zmask
+        self.ctx_unet = (self._static_set("k_unet", k), self._static_set("vt_unet", vt), s, sp, zmask)
         self.cond = None
         if self.controlnet is not None:
             if guess_mode and b > 1:
@@ -92,8 +95,11 @@ class DenoiseLoop:
             if self.controlnet._run_dtype() != self.dtype:
                 raise RuntimeError("UNet and ControlNet must run in the same 16-bit dtype inside the fused loop")
             self.cond = self._static_set("cond", f32(controlnet_cond).reshape(f, 4, h, w))
-            k, vt, s, sp = self.controlnet.project_context(ehs)
-            self.ctx_cn = (self._static_set("k_cn", k), self._static_set("vt_cn", vt), s, sp)
+            k, vt, s, sp, zmask_cn = self.controlnet.project_context(ehs)
+            if self._static.setdefault("zero_ctx_mask_cn", zmask_cn) != zmask_cn:
+                self._graph = self._graph_off = None
+                self._static["zero_ctx_mask_cn"] = zmask_cn
+            self.ctx_cn = (self._static_set("k_cn", k), self._static_set("vt_cn", vt), s, sp, zmask_cn)
             self.cn_scales = self.controlnet._scales(float(conditioning_scale), bool(guess_mode), len(self.controlnet.controlnet_down_blocks))
             if self._static.setdefault("cn_scales", self.cn_scales) != self.cn_scales:
                 self._graph = None              # the scale is a launch argument baked into the graph

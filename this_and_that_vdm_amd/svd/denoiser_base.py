@@ -2,6 +2,8 @@
 path, the per-request context K/V projection and the encoder walk."""
 from __future__ import annotations
 
+import os
+
 from typing import List, Optional, Tuple
 
 import torch
@@ -34,6 +36,9 @@ class DenoiserBase(ModelMixin):
     # "fp8 MFMA attention path"); projections write e4m3 directly, softmax / accumulation stay fp32.  Lower precision than the
     # default 16-bit path (3 mantissa bits on Q, K, V, P): tests/test_ops_gpu.py::test_attention_fp8 states the tolerance.
     attention_fp8: bool = False
+    # Skip the cross-attention arithmetic of batch elements whose context is all zeros (see project_context): exact, on by
+    # default; TT_ZERO_CTX=0 or setting this to False keeps the general path (A/B measurements, tests).
+    zero_context_shortcut: bool = os.environ.get("TT_ZERO_CTX", "1") != "0"
 
     # ---- packing
     _pack_gen = 0          # bumped by every (re)pack: consumers holding raw pointers to packed buffers (captured
@@ -102,12 +107,21 @@ class DenoiserBase(ModelMixin):
         pad = pad.view(b * sp, d)
         k_all = ops.gemm(pad, self._k_w)                              # [B*Sp, sumC]
         vt_all = ops.gemm(self._v_w, pad)                             # [sumC, B*Sp]
-        return (k_all, vt_all, s, sp)
+        # Batch elements whose context is ALL zeros (the CFG uncond half: `negative_image_embeddings = zeros_like`, reference
+        # pipeline :145-152, quirk Q8): to_k / to_v have no bias, so K = V = 0, every score is 0, softmax is uniform over
+        # zero values and the cross-attention output is exactly 0 -- the layer reduces to to_out's bias.  The spatial
+        # transformer blocks skip the query projection / attention / output projection for those rows (layers.py).
+        # One host read per request (step-invariant); bit i = batch element i.
+        zero_mask = 0
+        if self.zero_context_shortcut:
+            flags = (pad.view(b, -1) == 0).all(1).tolist()
+            zero_mask = sum(1 << i for i, z in enumerate(flags) if z)
+        return (k_all, vt_all, s, sp, zero_mask)
 
     def _step_context(self, emb: torch.Tensor, context) -> StepContext:
         film = ops.small_linear(emb, self._film_w, self._film_b, act_in=True)     # every ResBlock's FiLM row at once
-        k_all, vt_all, s, sp = context
-        return StepContext(film, k_all, vt_all, s, sp, attn_fp8=bool(self.attention_fp8))
+        k_all, vt_all, s, sp, zero_mask = context
+        return StepContext(film, k_all, vt_all, s, sp, attn_fp8=bool(self.attention_fp8), zero_mask=zero_mask)
 
     # ---- encoder walk shared by both models
     def _encode(self, x, g: Geom, ctx: StepContext):

@@ -56,9 +56,24 @@ class StepContext:
     cross-attention K / V^T of every attention layer (two GEMMs per request, step-invariant)."""
 
     def __init__(self, film: torch.Tensor, k_all: torch.Tensor, vt_all: torch.Tensor, s_ctx: int, s_pad: int,
-                 attn_fp8: bool = False):
+                 attn_fp8: bool = False, zero_mask: int = 0):
         self.film, self.k_all, self.vt_all, self.s_ctx, self.s_pad = film, k_all, vt_all, s_ctx, s_pad
         self.attn_fp8 = attn_fp8            # spatial self-attention on e4m3 operands (BASELINE config 5)
+        self.zero_mask = zero_mask          # bit b: the context of batch element b is all zeros (denoiser_base.project_context)
+
+    def live_batches(self, g: "Geom"):
+        """Which batch elements of launch `g` need real cross-attention.  None: all of them (general path).  Otherwise
+        (first, count): elements [first, first+count) of the launch have a non-zero context and every other one an all-zero
+        context, whose cross-attention output is exactly 0 (count may be 0)."""
+        flags = [(self.zero_mask >> (g.batch0 + i)) & 1 for i in range(g.batch)]
+        if not any(flags):
+            return None
+        live = [i for i, z in enumerate(flags) if not z]
+        if not live:
+            return (0, 0)
+        if live[-1] - live[0] + 1 != len(live):
+            return None                     # live elements not contiguous in the row order: keep the general path
+        return (live[0], len(live))
 
     _VT_CACHE: Dict[tuple, torch.Tensor] = {}
 
@@ -416,11 +431,37 @@ class BasicTransformerBlock(_Packable):
         self.kv = reg.add_kv(self.attn2.to_k, self.attn2.to_v)
         self.ff.pack(reg, dtype, norm=self.norm3)
 
+    def _zero_ctx_rows(self, ctx: StepContext, g: Geom) -> torch.Tensor:
+        """fp32 [g.batch, C]: to_out's bias of the cross-attention for batch elements with an all-zero context, 0 for the others
+        (cached per mask: built once, outside graph capture)."""
+        cache = self.__dict__.setdefault("_zrows", {})
+        key = (ctx.zero_mask, g.batch0, g.batch, self.bo2.data_ptr())
+        rows = cache.get(key)
+        if rows is None:
+            flags = [float((ctx.zero_mask >> (g.batch0 + i)) & 1) for i in range(g.batch)]
+            rows = cache[key] = (torch.tensor(flags, dtype=torch.float32, device=self.bo2.device)[:, None] * self.bo2[None, :]).contiguous()
+        return rows
+
     def forward(self, x, g: Geom, ctx: StepContext):
         a = _self_attention(x, self.attn1, self.wqk, self.bqk, self.wv, self.norm1.eps, g, ctx)
-        x = ops.gemm(a, self.wo1, bias=self.bo1, residual=x)
-        a = _cross_attention(x, self.attn2, self.wq2, self.bq2, self.norm2.eps, self.kv, g, ctx, temporal=False)
-        x = ops.gemm(a, self.wo2, bias=self.bo2, residual=x)
+        live = ctx.live_batches(g)
+        if live is None:
+            x = ops.gemm(a, self.wo1, bias=self.bo1, residual=x)
+            a = _cross_attention(x, self.attn2, self.wq2, self.bq2, self.norm2.eps, self.kv, g, ctx, temporal=False)
+            x = ops.gemm(a, self.wo2, bias=self.bo2, residual=x)
+            return self.ff(x, residual=x)
+        # Batch elements with an all-zero context (the CFG uncond half): K = V = 0, so their cross-attention output is exactly 0
+        # and the layer adds to_out's bias only -- that bias rides on the self-attention output projection as a per-batch row
+        # vector, and query projection / attention / output projection run on the rows of the live elements alone (in place:
+        # every lane of the GEMM epilogue reads the residual element it overwrites).
+        first, count = live
+        x = ops.gemm(a, self.wo1, bias=self.bo1, residual=x, rowvec=self._zero_ctx_rows(ctx, g), rowvec_rows=g.frames * g.hw)
+        if count:
+            rows = g.frames * g.hw
+            xs = x[first * rows:(first + count) * rows]
+            gl = Geom(count, g.frames, g.h, g.w, g.batch0 + first, g.ctx_batches)
+            a = _cross_attention(xs, self.attn2, self.wq2, self.bq2, self.norm2.eps, self.kv, gl, ctx, temporal=False)
+            ops.gemm(a, self.wo2, bias=self.bo2, residual=xs, out=xs)
         return self.ff(x, residual=x)
 
 
