@@ -8,7 +8,7 @@ import subprocess
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(_HERE, "csrc")
-LIB_PATH = os.path.join(CSRC, "libttvdm.so")
+LIB_PATH = os.environ.get("TT_LIBTTVDM") or os.path.join(CSRC, "libttvdm.so")      # TT_LIBTTVDM: A/B builds of the same ABI
 
 TT_BF16, TT_F16, TT_F32 = 0, 1, 2
 

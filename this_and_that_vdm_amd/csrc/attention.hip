@@ -588,37 +588,67 @@ __global__ __launch_bounds__(128) void tattn_kernel(const char* qkv, long ldqkv,
 #pragma unroll
     for (int c = 0; c < D / EPC; ++c) qv[c] = *(const uint4*)(qp + c * 16);
   }
-  // stage K and V rows: unit u, frame f
+  // stage K and V rows: unit u, frame f.  16-bit, D = 64: K and V share ONE LDS buffer (V waits in registers while the scores
+  // are computed), which halves the LDS per block -- 8 blocks = 16 waves per CU instead of 8; the kernel is a latency-bound
+  // HBM stream (load -> barrier -> score chains -> P.V in series per block), so resident waves are what hides the loads.
+#ifdef TT_TATTN_NO_REUSE
+  constexpr bool REUSE = false;
+#else
+  constexpr bool REUSE = ES == 2 && D == 64;
+#endif
   const int chunks_per_row = D / EPC;
   const int nchunks = UPB * frames * chunks_per_row;
-  for (int tensor = 0; tensor < 2; ++tensor) {
-    char* dst = smem + tensor * (UPB * UNITB);
-    for (int s = tid; s < nchunks; s += 128) {
-      const int c = s % chunks_per_row, rf = s / chunks_per_row;
-      const int f = rf % frames, ul = rf / frames;
-      const long su = u0 + ul;
-      uint4 v = make_uint4(0, 0, 0, 0);
-      if (su < total_units) {
-        const int sh = (int)(su % heads);
-        const long sbp = su / heads;
-        const int spix = (int)(sbp % hw);
-        const int sb = (int)(sbp / hw);
-        const long row = ((long)sb * frames + f) * hw + spix;
-        v = *(const uint4*)(qkv + (row * ldqkv + (tensor + 1) * C + sh * D + c * EPC) * ES);
+  constexpr int MAXI = REUSE ? (UPB * LPU * (D / EPC) + 127) / 128 : 1;
+  auto src_of = [&](int s, int tensor, int& ldsoff) -> const char* {
+    const int c = s % chunks_per_row, rf = s / chunks_per_row;
+    const int f = rf % frames, sul = rf / frames;
+    const long su = u0 + sul;
+    ldsoff = sul * UNITB + f * ROWB + c * 16;
+    if (su >= total_units) return nullptr;
+    const int sh = (int)(su % heads);
+    const long sbp = su / heads;
+    const int spix = (int)(sbp % hw);
+    const int sb = (int)(sbp / hw);
+    const long row = ((long)sb * frames + f) * hw + spix;
+    return qkv + (row * ldqkv + (tensor + 1) * C + sh * D + c * EPC) * ES;
+  };
+  uint4 vreg[MAXI];
+  int off[MAXI];
+  if constexpr (REUSE) {
+    uint4 kreg[MAXI];
+#pragma unroll
+    for (int i = 0; i < MAXI; ++i) {
+      const int s_ = tid + i * 128;
+      kreg[i] = vreg[i] = make_uint4(0, 0, 0, 0);
+      off[i] = -1;
+      if (s_ < nchunks) {
+        const char* kp = src_of(s_, 0, off[i]);
+        if (kp) { kreg[i] = *(const uint4*)kp; vreg[i] = *(const uint4*)(kp + (long)C * ES); }
       }
-      *(uint4*)(dst + ul * UNITB + f * ROWB + c * 16) = v;
+    }
+#pragma unroll
+    for (int i = 0; i < MAXI; ++i)
+      if (off[i] >= 0) *(uint4*)(smem + off[i]) = kreg[i];
+  } else {
+    for (int tensor = 0; tensor < 2; ++tensor) {
+      char* dst = smem + tensor * (UPB * UNITB);
+      for (int s_ = tid; s_ < nchunks; s_ += 128) {
+        int o;
+        const char* sp = src_of(s_, tensor, o);
+        *(uint4*)(dst + o) = sp ? *(const uint4*)sp : make_uint4(0, 0, 0, 0);
+      }
     }
   }
   __syncthreads();
-  if (!active) return;
   const char* ks = smem + ul * UNITB;
-  const char* vs = smem + UPB * UNITB + ul * UNITB;
+  const char* vs = smem + (REUSE ? 0 : UPB * UNITB) + ul * UNITB;
   float sc[LPU];
   float mx = -INFINITY;
+  if constexpr (!REUSE) { if (!active) return; }
 #pragma unroll
   for (int j = 0; j < LPU; ++j) {
     float a = 0.f;
-    if (j < frames) {
+    if (j < frames && active) {
       float a1 = 0.f;        // two accumulation chains
 #pragma unroll
       for (int c = 0; c < D / EPC; ++c) {
@@ -644,6 +674,14 @@ __global__ __launch_bounds__(128) void tattn_kernel(const char* qkv, long ldqkv,
 #pragma unroll
   for (int j = 0; j < LPU; ++j) { sc[j] = j < frames ? exp2f(sc[j] - mx) : 0.f; sum += sc[j]; }
   const float inv = 1.0f / sum;
+  if constexpr (REUSE) {
+    __syncthreads();                                   // every lane is done with K
+#pragma unroll
+    for (int i = 0; i < MAXI; ++i)
+      if (off[i] >= 0) *(uint4*)(smem + off[i]) = vreg[i];
+    __syncthreads();
+    if (!active) return;
+  }
   float acc[D];
 #pragma unroll
   for (int e = 0; e < D; ++e) acc[e] = 0.f;
@@ -668,7 +706,12 @@ __global__ __launch_bounds__(128) void tattn_kernel(const char* qkv, long ldqkv,
 template <typename Tag, int D, int LPU>
 void launch_tattn(const void* qkv, long ldqkv, void* out, long ldo, int batch, int frames, int hw, int heads, hipStream_t st) {
   constexpr int UPB = 128 / LPU;
-  constexpr size_t lds = 2 * UPB * (LPU * (D * Elem<Tag>::ES + 16) + 64);
+#ifdef TT_TATTN_NO_REUSE
+  constexpr bool REUSE = false;
+#else
+  constexpr bool REUSE = Elem<Tag>::ES == 2 && D == 64;      // K and V share the buffer (tattn_kernel)
+#endif
+  constexpr size_t lds = (REUSE ? 1 : 2) * UPB * (LPU * (D * Elem<Tag>::ES + 16) + 64);
   static_assert(lds <= 160 * 1024, "temporal attention staging exceeds the LDS");
   static unsigned long long attr_done = 0;
   tt_lds_opt_in((const void*)tattn_kernel<Tag, D, LPU>, (int)lds, &attr_done);
