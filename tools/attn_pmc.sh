@@ -5,14 +5,17 @@ set -u
 out=${1:-gpurun_out/attn_pmc}; mkdir -p $out
 cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
 timeout 300 rocprofv3 --pmc SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_INSTS_VALU SQ_INSTS_MFMA SQ_VALU_MFMA_BUSY_CYCLES SQ_ACTIVE_INST_VALU SQ_WAIT_INST_ANY SQ_WAIT_ANY \
-  --kernel-trace --kernel-include-regex "attn_kernel" --output-format csv -d $out/raw -o p -- python tools/attn_bench.py > $out/run.log 2>&1
+  --kernel-trace --kernel-include-regex "attn_kernel|attn8_kernel" --output-format csv -d $out/raw -o p -- python tools/attn_bench.py > $out/run.log 2>&1
 python - "$out" <<'PY'
 import csv, glob, sys, collections, os
 out = sys.argv[1]
 acc = collections.defaultdict(lambda: collections.defaultdict(list))
 for f in glob.glob(os.path.join(out, "raw", "**", "*counter_collection.csv"), recursive=True):
     for r in csv.DictReader(open(f)):
-        key = (r["Kernel_Name"].split("(")[0][-40:], r["Grid_Size"] if "Grid_Size" in r else r.get("Grid_Size_X", ""))
+        import re
+        m = re.search(r"(attn8?_kernel<[^>]*>)", r["Kernel_Name"])
+        gs = int(r["Grid_Size"] if "Grid_Size" in r else r.get("Grid_Size_X", "0"))
+        key = (m.group(1) if m else r["Kernel_Name"][-40:], f"{gs // 256} blocks of 256 threads")
         acc[key][r["Counter_Name"]].append(float(r["Counter_Value"]))
 with open(os.path.join(out, "attn_sq_counters.txt"), "w") as w:
     for key, c in acc.items():
