@@ -60,6 +60,8 @@ const char* tt_last_error(void);
  *   v = (acc + bias[n]) * acc_scale + rowvec[m / rowvec_rows][n]
  *   geglu: v = v_value * gelu_erf(v_gate)      (W rows pre-interleaved in 16-row groups: 8 value, 8 gate)
  *   v += residual[m][n];  v = alpha*blend[m][n] + (1-alpha)*v   (AlphaBlender, video branch)
+ * `out` may alias `residual` (same pointer and stride: in-place update of the hidden states -- every element's residual is
+ * read by the lane that writes it, in the tile kernels and in the split-K reduction); it must not alias a0 / a1 / blend.
  * ---------------------------------------------------------------------------------------------- */
 typedef struct TtGemmArgs {
   const void* a0; const void* a1;      /* activation sources; a1 NULL if k1 == 0 */
