@@ -234,6 +234,10 @@ def main():
         if m is not None:
             m.attention_fp8 = a.attn == "fp8"
     loop, args = make_loop(unet, cn, a.res, device, seed=rank)
+    if os.environ.get("TT_NO_OVERLAP") == "1":          # experiment switches: GestureNet and UNet encoder on ONE stream
+        loop.overlap_branches = False
+    if os.environ.get("TT_SPLIT_CFG") == "1":           # ... the two CFG halves as separate graph branches
+        loop.split_cfg = True
 
     def fence():
         torch.cuda.synchronize()
