@@ -59,6 +59,13 @@ int forced_cfg() {
   return g_forced_cfg;
 }
 
+// tuning switch: TT_GEMM_GROUP_M=<rows> overrides the group height of the tile order (gemm_kernel.h: launch_cfg picks it otherwise)
+int g_group_m = -2;
+int group_m_override() {
+  if (g_group_m == -2) { const char* e = getenv("TT_GEMM_GROUP_M"); g_group_m = e ? atoi(e) : 0; }
+  return g_group_m;
+}
+
 int g_forced_split = -2;
 int forced_split() {
   if (g_forced_split == -2) { const char* e = getenv("TT_GEMM_SPLITK"); g_forced_split = e ? atoi(e) : -1; }
@@ -235,7 +242,7 @@ extern "C" int tt_gemm(const TtGemmArgs* a, tt_stream_t stream) {
   }
   hipStream_t st = (hipStream_t)stream;
   if (sq320_ok(a)) {
-    p.splitk = 1; p.ws = nullptr; p.ws_bytes = 0;
+    p.splitk = 1; p.ws = nullptr; p.ws_bytes = 0; p.group_m_override = 0; p.group_m = 1;
     if (a->dtype == TT_BF16) launch_sq320_bf16(p, st); else launch_sq320_f16(p, st);
     TT_CHECK_LAUNCH("tt_gemm");
     return TT_OK;
@@ -246,6 +253,7 @@ extern "C" int tt_gemm(const TtGemmArgs* a, tt_stream_t stream) {
   if (pl.splitk > 1 && (long)pl.splitk * a->m * a->n * 4 >= (1L << 31))
     pl = Plan{make_plan(a->m, a->n, 0, false, !(a->residual || a->blend || a->rowvec)).cfg, 1};            // slabs beyond the 32-bit offsets: un-split plan
   p.splitk = pl.splitk;
+  p.group_m_override = group_m_override(); p.group_m = 1;
   p.ws = (float*)a->ws;
   p.ws_bytes = pl.splitk > 1 ? (unsigned)((long)pl.splitk * a->m * a->n * 4) : 0u;
   if (a->dtype == TT_BF16) launch_bf16(p, pl.cfg, st);

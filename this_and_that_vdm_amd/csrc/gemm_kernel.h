@@ -24,6 +24,8 @@ struct GemmP {
   int out_col_hw, out_col_hwp;
   int nk0, nk1, taps, kt_total;     // derived: K steps per source, taps, total K steps
   int tiles_m, tiles_n;
+  int group_m_override;             // > 0: host override (TT_GEMM_GROUP_M), else launch_cfg picks
+  int group_m;                      // tile rows per group of the launch order (>= 1; see the tile mapping in gemm_kernel)
   unsigned a0_bytes, a1_bytes, w_bytes;   // extents for the buffer descriptors (< 2 GiB each)
   unsigned out_bytes, res_bytes, blend_bytes, bias_bytes, rowvec_bytes, ws_bytes;   // epilogue descriptors (0 = absent)
   int splitk;                       // > 1: block (tile, s) reduces K slice s and writes an fp32 slab to ws
@@ -242,7 +244,22 @@ void gemm_kernel(const GemmP p) {
   }
   const int split = p.splitk > 1 ? bid % p.splitk : 0;      // slices of one tile sit next to each other
   if (p.splitk > 1) bid /= p.splitk;
-  const int tile_m = bid / p.tiles_n, tile_n = bid - tile_m * p.tiles_n;
+  // Within an XCD's run the tiles go in groups of `group_m` tile rows, column by column inside a group: the ~64 workgroups
+  // that are resident on an XCD at a time then cover group_m rows x 64/group_m columns, i.e. every K slice they fetch is
+  // shared by group_m (W) or 64/group_m (A) of them instead of the whole window sharing ONE A row and streaming every W
+  // column.  The K loop is bound by the LDS fill (ablation in DESIGN.md section 6: without the loads the same loop runs
+  // ~2x faster, without the MFMAs only ~1.2x), and what misses L2 pays the fabric latency.
+  int tile_m, tile_n;
+  {
+    const int gm = p.group_m;
+    const int per_group = gm * p.tiles_n;
+    const int grp = bid / per_group;
+    const int first = grp * gm;
+    const int rows = min(gm, p.tiles_m - first);
+    const int r = bid - grp * per_group;
+    tile_n = r / rows;
+    tile_m = first + (r - tile_n * rows);
+  }
   const int m0 = tile_m * BM, n0 = tile_n * BN;
   // K-tile range of this block
   const int kt_lo = (int)((long)p.kt_total * split / p.splitk);
@@ -978,6 +995,20 @@ template <typename Tag, int BM, int BN, int BK, int NST, int WGM, int WGN, bool 
 void launch_cfg(GemmP& p, hipStream_t st) {
   p.tiles_m = ceil_div(p.m, BM);
   p.tiles_n = ceil_div(p.n, BN);
+  {
+    // group height that balances the A rows and W columns of one XCD's resident window (32 CUs x blocks per CU)
+    constexpr int NT_ = 64 * WGM * WGN, CPR_ = BK / Elem<Tag>::EPC;
+    constexpr long lds_ = (long)NST * (((BM * CPR_ + NT_ - 1) / NT_) + ((BN * CPR_ + NT_ - 1) / NT_)) * NT_ * 16;
+    const int window = 32 * (lds_ * 2 <= 160 * 1024 ? 2 : 1);
+    int gm = p.group_m_override;
+    if (gm <= 0) {
+      gm = 1;
+      // few columns: a row's tiles are all resident together anyway and row-major keeps neighbouring rows (conv halos) adjacent
+      if (p.tiles_n > 8)
+        while (gm * 2 * BM * gm * 2 <= (long)window * BN && gm * 2 <= p.tiles_m) gm *= 2;    // gm^2 * BM <= window * BN
+    }
+    p.group_m = gm < 1 ? 1 : (gm > p.tiles_m ? p.tiles_m : gm);
+  }
   p.nk0 = ceil_div(p.k0, BK); p.nk1 = p.k1 ? ceil_div(p.k1, BK) : 0;
   p.kt_total = p.taps * (p.nk0 + p.nk1);
   if constexpr (LNOK) {
