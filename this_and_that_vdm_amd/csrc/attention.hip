@@ -33,6 +33,24 @@ constexpr int KB = 64;    // keys per tile
 // raw v_exp_f32: inputs here are <= 0 or -inf (exp2(-inf) = 0), no denormal/range fix-ups needed
 __device__ __forceinline__ float fast_exp2(float x) { return __builtin_amdgcn_exp2f(x); }
 
+// XCD-aware block order (cdna guide T1, bijective form): the dispatcher places linear block b on XCD b % 8; remap so that each
+// XCD runs a CONTIGUOUS range of logical blocks, x fastest -- the query blocks of one (head, sequence) then share an XCD and its
+// L2 keeps their K / V^T (every query block streams all of them) instead of all eight L2s fetching a copy through the fabric.
+struct Bid3 { int x, y, z; };
+__device__ __forceinline__ Bid3 xcd_remap3() {
+  const int gx = gridDim.x, gy = gridDim.y;
+  const int nwg = gx * gy * (int)gridDim.z;
+  int bid = (int)blockIdx.x + gx * ((int)blockIdx.y + gy * (int)blockIdx.z);
+  const int q = nwg >> 3, r = nwg & 7, xcd = bid & 7, idx = bid >> 3;
+  bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
+  Bid3 o;
+  o.x = bid % gx;
+  const int t = bid / gx;
+  o.y = t % gy;
+  o.z = t / gy;
+  return o;
+}
+
 template <typename Tag, int D, int MASK>
 __global__ __launch_bounds__(256, (D == 64 && Elem<Tag>::ES == 2) ? 2 : 1) void attn_kernel(const AttnP p) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -51,7 +69,8 @@ __global__ __launch_bounds__(256, (D == 64 && Elem<Tag>::ES == 2) ? 2 : 1) void 
   const int tid = threadIdx.x, lane = tid & 63;
   const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int l31 = lane & 31, hi = lane >> 5;
-  const int head = blockIdx.y, seq = blockIdx.z;
+  const Bid3 blk = xcd_remap3();
+  const int head = blk.y, seq = blk.z;
   const char* zero = (const char*)tt_zero_page;
 
   // ---- which queries does this block own, which keys do they see.
@@ -60,8 +79,8 @@ __global__ __launch_bounds__(256, (D == 64 && Elem<Tag>::ES == 2) ? 2 : 1) void 
   // the context is block-uniform and the block stages only that context's keys (2 tiles of 64 for 78 tokens, instead of
   // 3 masked tiles over both contexts with a division per score).
   const int qstride = MASK == 2 ? p.ctx_batches : 1;
-  const int qcls = MASK == 2 ? (int)blockIdx.x % qstride : 0;
-  const int qblk = MASK == 2 ? (int)blockIdx.x / qstride : (int)blockIdx.x;
+  const int qcls = MASK == 2 ? blk.x % qstride : 0;
+  const int qblk = MASK == 2 ? blk.x / qstride : blk.x;
   int kbase, vbase;
   if (MASK == 0) { kbase = seq * p.k_seq_stride; vbase = seq * p.v_seq_stride; }
   else {
@@ -321,7 +340,8 @@ __global__ __launch_bounds__(256, 2) void attn8_kernel(const AttnP p) {
   const int tid = threadIdx.x, lane = tid & 63;
   const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int l31 = lane & 31, hi = lane >> 5;
-  const int head = blockIdx.y, seq = blockIdx.z, qblk = blockIdx.x;
+  const Bid3 blk = xcd_remap3();
+  const int head = blk.y, seq = blk.z, qblk = blk.x;
   const int kbase = seq * p.k_seq_stride, vbase = seq * p.v_seq_stride;
   const int ntiles = (p.lk + KB - 1) / KB;
   const int qrow = qblk * QB + wid * 32 + l31;
