@@ -67,6 +67,18 @@ def test_gemm_in_place_on_the_residual(ops, dtype, m, n, k):
     assert torch.equal(x[:32], keep[:32]) and torch.equal(x[32 + m:], keep[32 + m:])
 
 
+@pytest.mark.parametrize("dtype", DTYPES16)
+@pytest.mark.parametrize("m,n,k", [(1300, 2560, 192), (2900, 1408, 64), (9000, 1280, 128)])
+def test_gemm_grouped_tile_order(ops, dtype, m, n, k):
+    """More than 8 column tiles: the launch order walks groups of tile rows column by column (gemm_kernel.h).  Shapes whose
+    last group is ragged (11, 23 and 36 / 71 tile rows against groups of 8 / 4) must still cover every tile exactly once."""
+    a, w = rnd(m, k, dtype=dtype, seed=1), rnd(n, k, dtype=dtype, seed=2, scale=k ** -0.5)
+    out = torch.full((m + 8, n), 3.0, dtype=dtype, device="cuda")
+    ops.gemm(a.cuda(), w.cuda(), out=out[:m])
+    close(out[:m], a.float() @ w.float().T, dtype, scale=2.0)
+    assert (out[m:] == 3.0).all()
+
+
 @pytest.mark.parametrize("dtype", DTYPES)
 def test_gemm_is_transpose_safe(ops, dtype):
     """A = I with an asymmetric W: catches swapped row/col fragment maps (cdna guide rule 16)."""
