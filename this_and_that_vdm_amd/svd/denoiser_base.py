@@ -113,7 +113,8 @@ class DenoiserBase(ModelMixin):
         # transformer blocks skip the query projection / attention / output projection for those rows (layers.py).
         # One host read per request (step-invariant); bit i = batch element i.
         zero_mask = 0
-        if self.zero_context_shortcut:
+        # (the check reads the flags on the host: skipped while the caller is capturing a graph around forward())
+        if self.zero_context_shortcut and not torch.cuda.is_current_stream_capturing():
             flags = (pad.view(b, -1) == 0).all(1).tolist()
             zero_mask = sum(1 << i for i, z in enumerate(flags) if z)
         return (k_all, vt_all, s, sp, zero_mask)
