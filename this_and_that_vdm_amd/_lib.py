@@ -106,6 +106,11 @@ def load():
     if not os.path.exists(LIB_PATH):
         raise RuntimeError(f"{LIB_PATH} not found: run `make -C {CSRC}` (or __graft_entry__.build()). "
                            "There is no CPU/PyTorch fallback for the denoise path.")
+    # torch first: its wheel bundles its own HIP runtime (libamdhip64).  If libttvdm.so is dlopen'ed before torch, the system
+    # runtime it links against is the one that initialises, torch then brings a second copy, and kernels launched through this
+    # library fail with "no ROCm-capable device is detected" (seen with build() + smoke() in one process).  With torch loaded
+    # first the library's DT_NEEDED entry resolves to the runtime that owns torch's streams and allocations.
+    import torch  # noqa: F401
     lib = C.CDLL(LIB_PATH)
     for name, (res, args) in SIGNATURES.items():
         fn = getattr(lib, name)          # AttributeError here == ABI mismatch with include/ttvdm.h
