@@ -222,11 +222,19 @@ def main():
         return stub_cpu_main(a, world, rank)
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs MI355X GPUs (the denoise path has no CPU fallback)")
+    # TT_BENCH_ONE_GPU=1 (self-test on a 1-GPU box): every rank uses cuda:0 and the ranks talk over gloo -- the whole N > 1 code
+    # path (launcher, weight broadcast, barrier-bracketed timing, max over ranks) runs, only the numbers mean nothing
+    one_gpu = os.environ.get("TT_BENCH_ONE_GPU") == "1"
+    if one_gpu:
+        local = 0
     torch.cuda.set_device(local)
     device = torch.device("cuda", local)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        torch.distributed.init_process_group("nccl", device_id=device)
+        if one_gpu:
+            torch.distributed.init_process_group("gloo")
+        else:
+            torch.distributed.init_process_group("nccl", device_id=device)
     dtype = torch.bfloat16 if a.dtype == "bf16" else torch.float16
 
     unet, cn, bcast_s = build_models(a.mode, dtype, device, rank, world)
