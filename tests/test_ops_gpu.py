@@ -344,6 +344,32 @@ def test_groupnorm(ops, dtype, c0, c1, fpg, h, w):
 
 
 @pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("c0,c1,h,w,silu", [(1280, 1280, 8, 14, True), (640, 0, 16, 28, True), (1280, 0, 4, 7, False), (64, 32, 5, 3, True),
+                                            (320, 0, 40, 56, True)])
+def test_groupnorm_one_launch(ops, dtype, c0, c1, h, w, silu):
+    """ops.groupnorm: statistics + apply in one launch for small per-image problems (tt_groupnorm_small: several blocks per image,
+    each recomputing the image's statistics), the stats + apply pair otherwise (last case); equal to each other up to rounding
+    and to torch; canary columns behind a wider output stride stay untouched."""
+    nimg = 6
+    x0 = rnd(nimg, c0, h, w, dtype=dtype, seed=1, scale=3.0) + 1.5
+    x1 = rnd(nimg, c1, h, w, dtype=dtype, seed=2) if c1 else None
+    c = c0 + c1
+    gamma, beta = rnd(c, dtype=torch.float32, seed=3) + 1, rnd(c, dtype=torch.float32, seed=4)
+    xin = torch.cat([x0, x1], 1).float() if c1 else x0.float()
+    ref = F.group_norm(xin, 32, gamma, beta, eps=1e-5)
+    ref = (F.silu(ref) if silu else ref).permute(0, 2, 3, 1).reshape(-1, c)
+    tok = lambda t: t.permute(0, 2, 3, 1).reshape(-1, t.shape[1]).contiguous().cuda()
+    t0, t1 = tok(x0), (tok(x1) if c1 else None)
+    y = ops.groupnorm(t0, t1, nimg, h * w, 1, gamma.cuda(), beta.cuda(), 1e-5, silu)
+    close(y, ref, dtype, scale=2.0)
+    sc, sh = ops.groupnorm_stats(t0, t1, nimg, h * w, 1, gamma.cuda(), beta.cuda(), 1e-5)
+    y2 = ops.groupnorm_apply(t0, t1, nimg, h * w, sc, sh, silu)
+    close(y, y2.float().cpu(), dtype, scale=2.0)
+    small = bool(ops._lib.load().tt_groupnorm_small_supported(h * w, c, ops._code(dtype)))
+    assert small == (h * w * c * (4 if dtype == torch.float32 else 2) <= 640 * 1024)
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
 @pytest.mark.parametrize("c", [64, 320, 1280])
 def test_layernorm_and_fused_frame_embedding(ops, dtype, c):
     rows = 37 * 6

@@ -72,6 +72,8 @@ SIGNATURES = {
     "tt_conv3x3": (C.c_int, [C.POINTER(TtConvArgs), _vp]),
     "tt_temporal_attention": (C.c_int, [_vp, _i64, _vp, _i64, _i32, _i32, _i32, _i32, _i32, _i32, _vp]),
     "tt_groupnorm_ws_bytes": (_sz, [_i32, _i32, _i32]),
+    "tt_groupnorm_small_supported": (C.c_int, [_i32, _i32, _i32]),
+    "tt_groupnorm_small": (C.c_int, [_vp, _i32, _vp, _i32, _i32, _i32, _vp, _vp, _f32, _i32, _vp, _i64, _i32, _vp]),
     "tt_groupnorm_stats": (C.c_int, [_vp, _i32, _vp, _i32, _i32, _i32, _i32, _vp, _vp, _f32, _vp, _vp, _vp, _sz, _i32, _vp]),
     "tt_groupnorm_apply": (C.c_int, [_vp, _i32, _vp, _i32, _i32, _i32, _vp, _vp, _i32, _vp, _i64, _i32, _vp]),
     "tt_layernorm": (C.c_int, [_vp, _i64, _i32, _i32, _vp, _vp, _f32, _vp, _i32, _i32, _vp, _vp, _i64, _i32, _vp]),
@@ -115,7 +117,7 @@ def load():
     for name, (res, args) in SIGNATURES.items():
         fn = getattr(lib, name)          # AttributeError here == ABI mismatch with include/ttvdm.h
         fn.restype, fn.argtypes = res, args
-    if lib.tt_abi_version() != 3:
+    if lib.tt_abi_version() != 4:
         raise RuntimeError("libttvdm.so ABI version mismatch")
     _lib = lib
     return lib

@@ -122,10 +122,13 @@ __global__ __launch_bounds__(1024) void gn_finalize_kernel(const double* ws, int
 // few microseconds.  Thread = (row lane, 8-channel vector); fp32 sums per thread over its rows (8 loads in flight), combined
 // per group in fp64 in a fixed order (bit-reproducible), then scale/shift for every channel of the image.
 constexpr long GN_ONE_BYTES = 640 * 1024;
+// With y != nullptr the kernel also APPLIES the norm (tt_groupnorm_small): gridDim.y = S blocks per image, every one of them
+// computes the image's statistics (the same fixed-order arithmetic: identical results; the S-fold re-read is served by L2) and
+// then normalises + activates its own 1/S of the rows -- one launch instead of three for tensors whose GroupNorm is launch-bound.
 template <typename Tag>
 __global__ __launch_bounds__(1024) void gn_stats_image_kernel(const char* x0, int c0, const char* x1, int c1, int hw, int rpb,
                                                               const float* gamma, const float* beta, float eps,
-                                                              float* scale, float* shift) {
+                                                              float* scale, float* shift, char* y, long ldy, int silu) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   __shared__ float s_mean[GN_GROUPS], s_rstd[GN_GROUPS];
   const int C = c0 + c1, cv = C >> 3;
@@ -187,11 +190,41 @@ __global__ __launch_bounds__(1024) void gn_stats_image_kernel(const char* x0, in
     }
   }
   __syncthreads();
-  for (int c = tid; c < C; c += 1024) {
-    const int gg = c / cpg;
-    const float sc = s_rstd[gg] * gamma[c];
-    scale[(long)img * C + c] = sc;
-    shift[(long)img * C + c] = beta[c] - s_mean[gg] * sc;
+  if (y == nullptr) {
+    for (int c = tid; c < C; c += 1024) {
+      const int gg = c / cpg;
+      const float sc = s_rstd[gg] * gamma[c];
+      scale[(long)img * C + c] = sc;
+      shift[(long)img * C + c] = beta[c] - s_mean[gg] * sc;
+    }
+    return;
+  }
+  if (myr < rpb) {
+    const int ch = myv * 8;
+    float sc[8], sh[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      const int gg = (ch + e) / cpg;
+      sc[e] = s_rstd[gg] * gamma[ch + e];
+      sh[e] = beta[ch + e] - s_mean[gg] * sc[e];
+    }
+    const char* base; long ld; int coff;
+    if (ch < c0) { base = x0; ld = c0; coff = ch; } else { base = x1; ld = c1; coff = ch - c0; }
+    constexpr int ES = Elem<Tag>::ES;
+    const char* pbase = base + (((long)img * hw) * ld + coff) * ES;
+    char* ybase = y + (((long)img * hw) * ldy + ch) * ES;
+    const int S = gridDim.y, part = blockIdx.y;
+    const int r_lo = (int)((long)hw * part / S), r_hi = (int)((long)hw * (part + 1) / S);
+    for (int r = r_lo + myr; r < r_hi; r += rpb) {
+      float f[8];
+      load8<Tag>(pbase + (long)r * ld * ES, f);
+#pragma unroll
+      for (int e = 0; e < 8; ++e) {
+        const float t = fmaf(f[e], sc[e], sh[e]);
+        f[e] = silu ? silu_f(t) : t;
+      }
+      store8<Tag>(ybase + (long)r * ldy * ES, f);
+    }
   }
 }
 
@@ -273,6 +306,13 @@ __global__ __launch_bounds__(256) void ln_kernel(const char* x, long ldx, int ro
   }
 }
 
+// the per-image kernel keeps [rpb][C] x 2 fp32 partials in dynamic LDS (at most 96 KiB): ONE opt-in (per device) with that maximum
+constexpr int GN_IMAGE_LDS_MAX = 96 * 1024;
+template <typename Tag> static void gn_image_opt_in() {
+  static unsigned long long done = 0;
+  tt_lds_opt_in((const void*)gn_stats_image_kernel<Tag>, GN_IMAGE_LDS_MAX, &done);
+}
+
 }  // namespace
 
 extern "C" size_t tt_groupnorm_ws_bytes(int32_t nimg, int32_t hw, int32_t c) {
@@ -306,9 +346,8 @@ extern "C" int tt_groupnorm_stats(const void* x0, int32_t c0, const void* x1, in
     while (rpb1 > 1 && (size_t)2 * rpb1 * C * sizeof(float) > 96 * 1024) --rpb1;     // [rpb][C] x 2 fp32 in LDS
     if (rpb1 > hw) rpb1 = hw;
     const size_t lds1 = (size_t)2 * rpb1 * C * sizeof(float);
-    static unsigned long long attr_done[3] = {0, 0, 0};
-#define TT_GN1(TAG, IDX) do { tt_lds_opt_in((const void*)gn_stats_image_kernel<TAG>, (int)lds1, &attr_done[IDX]); \
-      hipLaunchKernelGGL(gn_stats_image_kernel<TAG>, dim3(nimg), dim3(1024), lds1, st, (const char*)x0, c0, (const char*)x1, c1, hw, rpb1, gamma, beta, eps, scale, shift); } while (0)
+#define TT_GN1(TAG, IDX) do { gn_image_opt_in<TAG>(); \
+      hipLaunchKernelGGL(gn_stats_image_kernel<TAG>, dim3(nimg), dim3(1024), lds1, st, (const char*)x0, c0, (const char*)x1, c1, hw, rpb1, gamma, beta, eps, scale, shift, (char*)nullptr, 0L, 0); } while (0)
     if (dtype == TT_BF16) TT_GN1(bf16_tag, 0); else if (dtype == TT_F16) TT_GN1(f16_tag, 1); else TT_GN1(f32_tag, 2);
 #undef TT_GN1
     TT_CHECK_LAUNCH("tt_groupnorm_stats");
@@ -323,6 +362,43 @@ extern "C" int tt_groupnorm_stats(const void* x0, int32_t c0, const void* x1, in
     hipLaunchKernelGGL(gn_partial_kernel<f32_tag>, dim3(chunks, nimg), dim3(threads), lds, st, (const char*)x0, c0, (const char*)x1, c1, hw, chunks, (double*)ws);
   hipLaunchKernelGGL(gn_finalize_kernel, dim3(nimg / fpg), dim3(32 * GN_SLICES), 0, st, (const double*)ws, chunks, hw, C, fpg, gamma, beta, eps, scale, shift);
   TT_CHECK_LAUNCH("tt_groupnorm_stats");
+  return TT_OK;
+}
+
+// ---- statistics + apply in one launch for small images (see gn_stats_image_kernel)
+static int gn_small_rpb(int C, int hw) {
+  const int cv = C >> 3;
+  int rpb = 1024 / cv;
+  while (rpb > 1 && (size_t)2 * rpb * C * sizeof(float) > 96 * 1024) --rpb;
+  if (rpb > hw) rpb = hw;
+  return rpb;
+}
+extern "C" int tt_groupnorm_small_supported(int32_t hw, int32_t c, int32_t dtype) {
+  const int es = dtype == TT_F32 ? 4 : 2;
+  return hw > 0 && c > 0 && (c % GN_GROUPS) == 0 && (c >> 3) <= 1024 && (long)hw * c * es <= GN_ONE_BYTES;
+}
+extern "C" int tt_groupnorm_small(const void* x0, int32_t c0, const void* x1, int32_t c1, int32_t nimg, int32_t hw,
+                                  const float* gamma, const float* beta, float eps, int32_t silu, void* y, int64_t ldy,
+                                  int32_t dtype, tt_stream_t stream) {
+  const int C = c0 + c1;
+  if (!x0 || !gamma || !beta || !y) TT_FAIL(TT_EINVAL, "tt_groupnorm_small: null operand");
+  if (c1 && !x1) TT_FAIL(TT_EINVAL, "tt_groupnorm_small: c1 without x1");
+  if (nimg <= 0 || (c0 & 7) || (c1 & 7) || (ldy & 7) || ldy < C) TT_FAIL(TT_EINVAL, "tt_groupnorm_small: channel counts/stride must be multiples of 8");
+  if (dtype != TT_BF16 && dtype != TT_F16 && dtype != TT_F32) TT_FAIL(TT_EINVAL, "tt_groupnorm_small: bad dtype");
+  if (!tt_groupnorm_small_supported(hw, C, dtype))
+    TT_FAIL(TT_EUNSUPPORTED, "tt_groupnorm_small: %d x %d per image is served by tt_groupnorm_stats + tt_groupnorm_apply", hw, C);
+  const int rpb = gn_small_rpb(C, hw);
+  const size_t lds = (size_t)2 * rpb * C * sizeof(float);
+  // blocks per image: enough to put the apply phase on ~4 x 28..56 CUs without re-reading the image too often
+  int parts = 4;
+  if (hw < parts * rpb) parts = hw / rpb > 0 ? hw / rpb : 1;
+  hipStream_t st = (hipStream_t)stream;
+#define TT_GNS(TAG, IDX) do { gn_image_opt_in<TAG>(); \
+    hipLaunchKernelGGL(gn_stats_image_kernel<TAG>, dim3(nimg, parts), dim3(1024), lds, st, (const char*)x0, c0, (const char*)x1, c1, hw, rpb, \
+                       gamma, beta, eps, (float*)nullptr, (float*)nullptr, (char*)y, (long)ldy, (int)silu); } while (0)
+  if (dtype == TT_BF16) TT_GNS(bf16_tag, 0); else if (dtype == TT_F16) TT_GNS(f16_tag, 1); else TT_GNS(f32_tag, 2);
+#undef TT_GNS
+  TT_CHECK_LAUNCH("tt_groupnorm_small");
   return TT_OK;
 }
 

@@ -247,6 +247,24 @@ def groupnorm_apply(x0, x1, nimg, hw, scale, shift, silu: bool, out=None):
     return out
 
 
+GN_SMALL = os.environ.get("TT_GN_SMALL", "1") != "0"      # A/B switch for the one-launch GroupNorm
+
+
+def groupnorm(x0, x1, nimg, hw, frames_per_group, gamma, beta, eps, silu: bool):
+    """act(group_norm(x0 | x1)) -> new tensor.  Small per-image problems take ONE launch (tt_groupnorm_small), everything else
+    tt_groupnorm_stats + tt_groupnorm_apply."""
+    lib = _lib.load()
+    c0 = x0.shape[-1]
+    c1 = 0 if x1 is None else x1.shape[-1]
+    if GN_SMALL and frames_per_group == 1 and lib.tt_groupnorm_small_supported(hw, c0 + c1, _code(x0.dtype)):
+        out = torch.empty((nimg * hw, c0 + c1), dtype=x0.dtype, device=x0.device)
+        check(lib.tt_groupnorm_small(_p(x0), c0, _p(x1), c1, nimg, hw, _p(gamma), _p(beta), eps, int(silu), _p(out), out.stride(0),
+                                     _code(x0.dtype), _stream()), "tt_groupnorm_small")
+        return out
+    sc, sh = groupnorm_stats(x0, x1, nimg, hw, frames_per_group, gamma, beta, eps)
+    return groupnorm_apply(x0, x1, nimg, hw, sc, sh, silu)
+
+
 def layernorm(x, gamma, beta, eps=1e-5, rowvec=None, rows_per_vec=0, nvec=0):
     """-> y, or (x + rowvec, y) when a row vector is fused in."""
     lib = _lib.load()

@@ -160,8 +160,7 @@ class TimestepEmbedding(_Packable):
 
 # --------------------------------------------------------------------------- resnets
 def _gn(x0, x1, g: Geom, frames_per_group, gamma, beta, eps, silu):
-    sc, sh = ops.groupnorm_stats(x0, x1, g.n, g.hw, frames_per_group, gamma, beta, eps)
-    return ops.groupnorm_apply(x0, x1, g.n, g.hw, sc, sh, silu)
+    return ops.groupnorm(x0, x1, g.n, g.hw, frames_per_group, gamma, beta, eps, silu)
 
 
 class ResnetBlock2D(_Packable):
@@ -201,14 +200,13 @@ class ResnetBlock2D(_Packable):
         fused = ops.CONV3X3_FUSED and ops.conv3x3_supported(g.h, g.w, c0, c1, self.out_channels, x0.dtype) and \
             ops.conv3x3_supported(g.h, g.w, self.out_channels, 0, self.out_channels, x0.dtype)
         conv = (g.n, g.h, g.w, g.h, g.w, 1, 0)
-        st1 = ops.groupnorm_stats(x0, x1, g.n, g.hw, 1, self.g1, self.be1, self.eps)
         if fused:
+            st1 = ops.groupnorm_stats(x0, x1, g.n, g.hw, 1, self.g1, self.be1, self.eps)
             hmid = ops.conv3x3(x0, x1, self.w1, g.n, g.h, g.w, gn=st1, silu=True, bias=self.b1, rowvec=film,
                                rowvec_rows=g.frames * g.hw)
         else:
-            a = ops.groupnorm_apply(x0, x1, g.n, g.hw, st1[0], st1[1], True)
+            a = ops.groupnorm(x0, x1, g.n, g.hw, 1, self.g1, self.be1, self.eps, True)
             hmid = ops.gemm(a, self.w1, mode=1, conv=conv, bias=self.b1, rowvec=film, rowvec_rows=g.frames * g.hw)
-        st2 = ops.groupnorm_stats(hmid, None, g.n, g.hw, 1, self.g2, self.be2, self.eps)
         if self.conv_shortcut is not None:
             xs = ops.gemm(x0, self.ws, a1=x1, bias=self.bs)
         else:
@@ -216,8 +214,9 @@ class ResnetBlock2D(_Packable):
                 raise RuntimeError("identity shortcut with a concatenated input")
             xs = x0
         if fused:
+            st2 = ops.groupnorm_stats(hmid, None, g.n, g.hw, 1, self.g2, self.be2, self.eps)
             return ops.conv3x3(hmid, None, self.w2, g.n, g.h, g.w, gn=st2, silu=True, bias=self.b2, residual=xs)
-        a = ops.groupnorm_apply(hmid, None, g.n, g.hw, st2[0], st2[1], True)
+        a = ops.groupnorm(hmid, None, g.n, g.hw, 1, self.g2, self.be2, self.eps, True)
         return ops.gemm(a, self.w2, mode=1, conv=conv, bias=self.b2, residual=xs)
 
 
