@@ -110,6 +110,7 @@ def test_zero_context_shortcut_and_general_path(dtype):
         ref = o_unet(x, t, ehs, ati)
         ops.attention = counting
         try:
+            p_unet.zero_context_shortcut = True             # (the class default follows TT_ZERO_CTX)
             got_short = p_unet(x.cuda(), t, ehs.cuda(), ati.cuda(), return_dict=False)[0]
             n_short, rows_short = len(rows), sum(rows)
             rows.clear()
