@@ -137,3 +137,34 @@ def test_zero_context_shortcut_and_general_path(dtype):
         rel, cos = LIMITS[dtype]
         for s in (s_short, s_full, s_2):
             assert s["rel_l2"] <= rel and s["cos"] >= cos, s
+
+
+@pytest.mark.gpu
+def test_zero_context_rows_follow_a_repack():
+    """The zero-context shortcut caches to_out's bias rows of the cross-attention (BasicTransformerBlock._zero_ctx_rows).
+    A repack (load_state_dict with another attn2.to_out[0].bias) must drop that cache: the new packed bias may be handed the
+    address of the old one by the caching allocator.  After each of two reloads the shortcut path has to agree with the
+    general path, which never touches the cache."""
+    if not torch.cuda.is_available():
+        pytest.skip("needs a GPU")
+    from tests.parity_common import build_pair, load_golden
+    g = load_golden("tiny_vgl")
+    p_unet, _, _, _ = build_pair("tiny_vgl", torch.float32, "cuda:0", False)
+    t = float(g["timestep"])
+    x, ehs, ati = g["sample"].cuda(), g["encoder_hidden_states"].cuda(), g["added_time_ids"].cuda()
+    sd = {k: v.clone() for k, v in p_unet.state_dict().items()}
+    keys = [k for k in sd if k.endswith("attn2.to_out.0.bias") and "temporal" not in k]
+    assert keys
+    outs = []
+    with torch.no_grad():
+        for rnd in range(3):
+            for k in keys:
+                sd[k] = torch.full_like(sd[k], 0.25 * (rnd + 1)) * (1 if rnd % 2 == 0 else -1)
+            p_unet.load_state_dict(sd)
+            p_unet.zero_context_shortcut = True
+            short = p_unet(x, t, ehs, ati, return_dict=False)[0].float().cpu()
+            p_unet.zero_context_shortcut = False
+            full = p_unet(x, t, ehs, ati, return_dict=False)[0].float().cpu()
+            torch.testing.assert_close(short, full, rtol=1e-3, atol=1e-4, msg=lambda m: f"reload {rnd}: {m}")
+            outs.append(full)
+    assert (outs[0] - outs[1]).abs().max() > 1e-3        # the bias change is visible in the output at all

@@ -429,6 +429,9 @@ class BasicTransformerBlock(_Packable):
         self.wo2, self.bo2 = cv(self.attn2.to_out[0].weight), _f32(self.attn2.to_out[0].bias)
         self.kv = reg.add_kv(self.attn2.to_k, self.attn2.to_v)
         self.ff.pack(reg, dtype, norm=self.norm3)
+        # rows built from the previous pack's bo2 must not survive a repack: the caching allocator can hand the new bo2 the
+        # address of an old one, so a data_ptr key alone would return the previous checkpoint's bias
+        self.__dict__.pop("_zrows", None)
 
     def _zero_ctx_rows(self, ctx: StepContext, g: Geom) -> torch.Tensor:
         """fp32 [g.batch, C]: to_out's bias of the cross-attention for batch elements with an all-zero context, 0 for the others
