@@ -29,7 +29,21 @@ sys.path.insert(0, REPO)
 STEP_TFLOP = {("vgl", "lo"): 20.10, ("vl", "lo"): 14.77, ("vgl", "hi"): 91.32, ("vl", "hi"): 66.89}
 LATENT = {"lo": (32, 56), "hi": (64, 112)}
 PEAK_TFLOPS = 2500.0          # dense bf16/fp16 MFMA peak, MI355X_MICROARCH.md (spec ~2.5 PF; 2495 measured)
+PEAK_TFLOPS_F32 = 157.3       # f32-input MFMA (v_mfma_f32_32x32x2_f32): the fp32 vector rate, same guide
 FRAMES, CTX_TOKENS, CTX_DIM, STEPS_PER_REQUEST = 14, 78, 1024, 25
+
+
+def csrc_hash() -> str:
+    """sha256[:16] over the kernel sources (csrc/*.hip, *.h, *.cpp, Makefile): identifies the binary a measurement belongs to."""
+    import glob
+    import hashlib
+    h = hashlib.sha256()
+    d = os.path.join(REPO, "this_and_that_vdm_amd", "csrc")
+    for f in sorted(glob.glob(os.path.join(d, "*.hip")) + glob.glob(os.path.join(d, "*.h")) + glob.glob(os.path.join(d, "*.cpp")) +
+                    [os.path.join(d, "Makefile")]):
+        h.update(os.path.basename(f).encode())
+        h.update(open(f, "rb").read())
+    return h.hexdigest()[:16]
 
 
 def build_models(mode, dtype, device, rank, world):
@@ -45,15 +59,20 @@ def build_models(mode, dtype, device, rank, world):
             cn = ControlNetModel().to(dtype).eval()
             models.append(("controlnet.", cn))
     from this_and_that_vdm_amd.dist import broadcast_model_, flat_param_buffer
-    bcast_s = None
+    bcast_s, checksum = None, 0
     for salt, m in models:
         flat = flat_param_buffer(m)
         if rank == 0:
             fill_parameters_(m, salt)            # zero-convs get non-zero values too
         if world > 1:
             bcast_s = (bcast_s or 0.0) + broadcast_model_(m, src=0, flat=flat)     # RCCL over xGMI, once
+        if dtype == torch.float32:
+            m.compute_dtype = torch.float32      # TT_F32 reference-precision mode (fp32 parameters default to bf16 compute)
+        # exact integer checksum of the parameter bytes (every rank must hold rank 0's weights after the broadcast)
+        bits = flat.view(torch.int16 if flat.element_size() == 2 else torch.int32)
+        checksum = (checksum * 1000003 + int(bits.to(torch.int64).sum().item())) % (1 << 61)
         m.prepare(force=True)
-    return unet, cn, bcast_s
+    return unet, cn, bcast_s, checksum
 
 
 def make_loop(unet, cn, res, device, seed):
@@ -154,6 +173,71 @@ def cpu_baseline(mode, res):
                       f"{mode.upper()} denoise step, CFG batch 2 x {FRAMES} frames at {h}x{w} latents = {step_s:.1f} s"}
 
 
+def block_main(a, dtype, device, peak) -> int:
+    """--block l0hi: ONE L0 TransformerSpatioTemporalModel (C = 320, 5 heads x 64) at 64x112 latents, CFG batch 2 x 14 frames,
+    78 context tokens with an all-zero uncond context as in the pipeline: the "14x4x64x112 spatio-temporal-attention block"
+    BASELINE's north_star prices against the MFMA roofline (reference svd/diffusion_arch/transformer_temporal.py:323-376).
+    Prints one JSON line; `roofline` is the whole block (algorithmic flops of its launches / block time)."""
+    from this_and_that_vdm_amd import ops
+    from this_and_that_vdm_amd.svd.diffusion_arch.transformer_temporal import TransformerSpatioTemporalModel
+    from this_and_that_vdm_amd.svd.layers import Geom, PackRegistry, StepContext
+    from this_and_that_vdm_amd.utils.synthetic import fill_parameters_
+    f, h, w, c, heads, b = FRAMES, 64, 112, 320, 5, 2
+    with torch.device(device):
+        blk = TransformerSpatioTemporalModel(heads, c // heads, in_channels=c, cross_attention_dim=CTX_DIM).eval()
+    fill_parameters_(blk, "l0tfm.")
+    reg = PackRegistry()
+    blk.pack(reg, dtype)
+    g = torch.Generator(device="cpu").manual_seed(4)
+    ehs = torch.nn.functional.layer_norm(torch.randn(b, CTX_TOKENS, CTX_DIM, generator=g), (CTX_TOKENS, CTX_DIM))
+    ehs[0] = 0                                                     # the CFG uncond half (pipeline :145-152)
+    sp = (CTX_TOKENS + 7) // 8 * 8
+    pad = torch.zeros(b, sp, CTX_DIM, dtype=dtype, device=device)
+    pad[:, :CTX_TOKENS] = ehs.to(device=device, dtype=dtype)
+    pad = pad.view(b * sp, CTX_DIM)
+    k_all = ops.gemm(pad, torch.cat(reg.k_w, 0).to(dtype).contiguous())
+    vt_all = ops.gemm(torch.cat(reg.v_w, 0).to(dtype).contiguous(), pad)
+    ctx = StepContext(None, k_all, vt_all, CTX_TOKENS, sp, attn_fp8=a.attn == "fp8", zero_mask=1)
+    geom = Geom(b, f, h, w)
+    tok = (torch.randn(geom.m, c, generator=g) * 1.0).to(device=device, dtype=dtype)
+    run = lambda: blk(tok, geom, ctx)
+    for _ in range(max(1, a.warmup)):
+        run()
+    torch.cuda.synchronize()
+    graph = torch.cuda.CUDAGraph()                                 # the block's ~45 launches replayed as in the step graph
+    with torch.cuda.graph(graph):
+        out = run()
+    graph.replay()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(a.steps):
+        graph.replay()
+    torch.cuda.synchronize()
+    ms = (time.perf_counter() - t0) / a.steps * 1e3
+    ops.PROFILE = []
+    run()
+    torch.cuda.synchronize()
+    rec, ops.PROFILE = ops.PROFILE, None
+    flops = sum(r[1] for r in rec)
+    agg = {}
+    for name, fl, e0, e1, _ in rec:
+        v = agg.setdefault(name, [0, 0.0, 0.0])
+        v[0] += 1; v[1] += fl; v[2] += e0.elapsed_time(e1) * 1e-3
+    line = {"metric": "L0 spatio-temporal transformer block at 64x112 latents (blocks/s)", "value": 1e3 / ms, "unit": "blocks/s", "n_gpus": 1,
+            "steps": a.steps, "warmup": a.warmup, "ms_per_step": ms, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": a.dtype, "data": "synthetic (random-init weights, seeded inputs)",
+            "config": {"workload": "one L0 TransformerSpatioTemporalModel (C 320, 5 heads x 64), CFG batch 2 x 14 frames x 7168 tokens, "
+                                   "78 context tokens (uncond context all zero), hipGraph replay", "spatial_self_attention": a.attn,
+                       "finite_output": bool(torch.isfinite(out.float()).all().item()), "block_tflop_algorithmic": flops / 1e12,
+                       "mfma_kernels": {k: {"launches": v[0], "tflop": v[1] / 1e12, "ms": v[2] * 1e3, "tflops": v[1] / v[2] / 1e12}
+                                        for k, v in sorted(agg.items(), key=lambda kv: -kv[1][2])}},
+            "roofline": {"bound": "mfma", "kernel": "whole block (all launches of one forward)", "achieved": flops / (ms * 1e-3) / 1e12,
+                         "peak": peak, "unit": "TFLOP/s", "frac": flops / (ms * 1e-3) / 1e12 / peak, "traffic": None},
+            "cpu_baseline": None}
+    print(json.dumps(line))
+    return 0
+
+
 def self_launch(n: int) -> int:
     """`python bench.py --gpus N` without a launcher: re-exec this script under torch.distributed.run with one rank per
     GPU of this node (127.0.0.1 rendezvous on a free port) -- exactly the command line the driver uses for N > 1."""
@@ -202,7 +286,10 @@ def main():
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--mode", choices=["vgl", "vl"], default="vgl")
     ap.add_argument("--res", choices=["lo", "hi"], default="lo")
-    ap.add_argument("--dtype", choices=["bf16", "fp16"], default="bf16")
+    ap.add_argument("--dtype", choices=["bf16", "fp16", "f32"], default="bf16",
+                    help="f32 = TT_F32 reference-precision mode (exact-fp32 MFMA, 1/16 of the bf16 rate): the price of meeting rtol 1e-3 / atol 1e-4")
+    ap.add_argument("--block", choices=["l0hi"], default=None,
+                    help="l0hi: time ONE L0 TransformerSpatioTemporalModel at 64x112 latents (BASELINE's spatio-temporal-attention block) instead of the step")
     ap.add_argument("--attn", choices=["bf16", "fp8"], default="bf16",
                     help="fp8: spatial self-attention on OCP e4m3 operands with fp8 MFMA (BASELINE config 5; 16-bit elsewhere)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -235,9 +322,14 @@ def main():
             torch.distributed.init_process_group("gloo")
         else:
             torch.distributed.init_process_group("nccl", device_id=device)
-    dtype = torch.bfloat16 if a.dtype == "bf16" else torch.float16
+    dtype = {"bf16": torch.bfloat16, "fp16": torch.float16, "f32": torch.float32}[a.dtype]
+    peak = PEAK_TFLOPS if a.dtype != "f32" else PEAK_TFLOPS_F32
+    if world > 1:                                # N ranks share the host's cores during prepare() / packing
+        torch.set_num_threads(max(1, min(8, (os.cpu_count() or 8) // world)))
+    if a.block:
+        return block_main(a, dtype, device, peak)
 
-    unet, cn, bcast_s = build_models(a.mode, dtype, device, rank, world)
+    unet, cn, bcast_s, checksum = build_models(a.mode, dtype, device, rank, world)
     for m in (unet, cn):
         if m is not None:
             m.attention_fp8 = a.attn == "fp8"
@@ -260,6 +352,14 @@ def main():
     fence()
     dt = time.perf_counter() - t0
     from this_and_that_vdm_amd.dist import max_over_ranks
+    per_rank_ms, checksums = [dt / a.steps * 1e3], [checksum]
+    if world > 1:
+        gdev = "cpu" if one_gpu else device
+        mine = torch.tensor([dt / a.steps * 1e3, float(checksum % (1 << 52))], dtype=torch.float64, device=gdev)
+        allv = [torch.zeros_like(mine) for _ in range(world)]
+        torch.distributed.all_gather(allv, mine)
+        per_rank_ms = [float(v[0]) for v in allv]
+        checksums = [int(v[1]) for v in allv]
     dt = max_over_ranks(dt, device)
     finite = bool(torch.isfinite(loop.result()).all().item())
 
@@ -271,16 +371,22 @@ def main():
         # HBM-side bytes per launch of that kernel: rocprofv3 PMC passes (FETCH_SIZE doubled, + WRITE_SIZE; tools/pmc_traffic.py)
         # cannot run inside this process, so the figure comes from the committed profile of the SAME kernel instance and is
         # stamped with where it was measured; it is null (not a stale number) when the dominant kernel has no entry there.
+        # It is reported only when that profile was taken on THIS binary (same hash of the kernel sources); otherwise null.
         traffic, traffic_src = None, None
-        tfile = os.path.join(REPO, "profiles", "r2_hbm_traffic.json")
+        tfile = os.path.join(REPO, "profiles", "r3_hbm_traffic.json")
         if os.path.exists(tfile):
             doc = json.load(open(tfile))
-            traffic = doc.get(f"{a.mode}_{a.res}", {}).get(name.replace("ttg::", ""))
-            if traffic is not None:
-                traffic_src = f"profiles/r2_hbm_traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, measured at commit {doc.get('_measured_at_commit', '?')})"
+            if doc.get("_kernel_source_sha16") == csrc_hash():
+                traffic = doc.get(f"{a.mode}_{a.res}", {}).get(name.replace("ttg::", ""))
+                if traffic is not None:
+                    traffic_src = ("profiles/r3_hbm_traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of tools/pmc_step.py on the "
+                                   f"same kernel sources, sha16 {doc.get('_kernel_source_sha16')})")
+            else:
+                traffic_src = ("null: profiles/r3_hbm_traffic.json was measured on other kernel sources "
+                               f"({doc.get('_kernel_source_sha16')} != {csrc_hash()}); re-run tools/profile_round.sh")
         roofline = {"bound": "mfma", "kernel": name, "launches_per_step": cnt,
-                    "achieved": fl / sec / 1e12, "peak": PEAK_TFLOPS, "unit": "TFLOP/s",
-                    "frac": fl / sec / 1e12 / PEAK_TFLOPS, "traffic": traffic, "traffic_source": traffic_src,
+                    "achieved": fl / sec / 1e12, "peak": peak, "unit": "TFLOP/s",
+                    "frac": fl / sec / 1e12 / peak, "traffic": traffic, "traffic_source": traffic_src,
                     "algorithmic_gflop_per_launch": fl / cnt / 1e9, "avg_launch_us": sec / cnt * 1e6}
         extras["mfma_kernels"] = {k: {"launches": v[0], "tflop": v[1] / 1e12, "ms": v[2] * 1e3,
                                       "tflops": v[1] / v[2] / 1e12} for k, v in sorted(agg.items(), key=lambda kv: -kv[1][2])}
@@ -294,7 +400,7 @@ def main():
         ms = dt / a.steps * 1e3
         step_tflop = STEP_TFLOP[(a.mode, a.res)]
         out = {
-            "metric": "denoise-steps/sec (14-frame 256x448 VGL, 25 steps)" if (a.mode, a.res, a.attn) == ("vgl", "lo", "bf16")
+            "metric": "denoise-steps/sec (14-frame 256x448 VGL, 25 steps)" if (a.mode, a.res, a.attn) == ("vgl", "lo", "bf16") and a.dtype != "f32"
                       else f"denoise-steps/sec (14-frame {h * 8}x{w * 8} {a.mode.upper()}{', fp8 attention' if a.attn == 'fp8' else ''}, 25 steps)",
             "value": world * a.steps / dt, "unit": "denoise-steps/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
             "ms_per_step": ms, "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": a.dtype,
@@ -306,8 +412,9 @@ def main():
                        "parallelism": f"{world} independent request(s), one per GPU; RCCL weight broadcast at start-up only",
                        "hipgraph": True, "finite_output": finite, "spatial_self_attention": a.attn,
                        "step_tflop_algorithmic": step_tflop,
-                       "step_mfma_frac_of_peak": step_tflop / (ms * 1e-3) / PEAK_TFLOPS,
-                       "weight_broadcast_s": bcast_s, **extras},
+                       "step_mfma_frac_of_peak": step_tflop / (ms * 1e-3) / peak,
+                       "weight_broadcast_s": bcast_s, "ms_per_step_per_rank": per_rank_ms,
+                       "weights_identical_on_all_ranks": len(set(checksums)) == 1, "kernel_source_sha16": csrc_hash(), **extras},
             "roofline": roofline, "cpu_baseline": cpu,
         }
         print(json.dumps(out))

@@ -102,3 +102,34 @@ def run_tiny_vgl_parity(dtype, device="cuda:0", name="tiny_vgl", strict=False):
         check(got, ref, "UNet (VGL) vs oracle")
         check(got, g["unet_vgl"], "UNet (VGL) vs reference-produced vectors")
     return stats
+
+
+@torch.no_grad()
+def autocast_yardstick(o_unet, o_cn, g, dtype):
+    """How far the reference's OWN 16-bit mode sits from its fp32 result: the oracle with its parameters cast to ``dtype`` under
+    ``torch.autocast`` (what test_code/inference.py:246 + accelerate's mixed precision do: models cast to weight_dtype, forward
+    under autocast) against the same oracle in fp32, on the same inputs.  Returns {name: err_stats} for the UNet (VL) output
+    and, with a ControlNet, the worst down residual, the mid residual and the UNet (VGL) output."""
+    import copy
+    t = float(g["timestep"])
+    x, ehs, ati = g["sample"], g["encoder_hidden_states"], g["added_time_ids"]
+    u16 = copy.deepcopy(o_unet).to(dtype)
+    lo = lambda v: v.to(dtype)
+    out = {}
+    ref = o_unet(x, t, ehs, ati)
+    with torch.autocast("cpu", dtype=dtype):
+        got = u16(lo(x), t, lo(ehs), lo(ati))
+    out["unet_vl"] = err_stats(got, ref)
+    if o_cn is not None:
+        cond = g["controlnet_cond"]
+        c16 = copy.deepcopy(o_cn).to(dtype)
+        rd, rm = o_cn(x, t, ehs, ati, controlnet_cond=cond, conditioning_scale=0.75)
+        with torch.autocast("cpu", dtype=dtype):
+            gd, gm = c16(lo(x), t, lo(ehs), lo(ati), controlnet_cond=lo(cond), conditioning_scale=0.75)
+        out["cn_down_worst"] = max((err_stats(a, b) for a, b in zip(gd, rd)), key=lambda s: s["rel_l2"])
+        out["cn_mid"] = err_stats(gm, rm)
+        ref2 = o_unet(x, t, ehs, ati, down_block_additional_residuals=rd, mid_block_additional_residual=rm)
+        with torch.autocast("cpu", dtype=dtype):
+            got2 = u16(lo(x), t, lo(ehs), lo(ati), down_block_additional_residuals=gd, mid_block_additional_residual=gm)
+        out["unet_vgl"] = err_stats(got2, ref2)
+    return out

@@ -184,8 +184,15 @@ def test_folded_layernorm_weights_keep_zero_row_sums_after_rounding(dtype):
     assert zs.dtype == dtype
     r_plain, r_zs = plain.double().sum(1).abs().max(), zs.double().sum(1).abs().max()
     assert r_zs <= 1e-5 and r_zs < r_plain / 100, (float(r_plain), float(r_zs))
-    # moving an element to its OTHER rounding neighbour costs at most 1.5 ulp of error against 0.5 for plain rounding
-    assert (zs.double() - wf.double()).abs().max() <= 3.01 * (plain.double() - wf.double()).abs().max()
+    # corrections go to elements whose own rounding error has the sign of the correction first: those land on their OTHER
+    # rounding neighbour (< 1 ulp from the true value, against <= 0.5 ulp for plain rounding)
+    mant, emin = (7, -126) if dtype == torch.bfloat16 else (10, -14)
+    _, e = torch.frexp(plain.double().abs())
+    ulp = 2.0 ** (torch.clamp(e - 1, min=emin) - mant).double()          # spacing in the binade of the rounded value
+    dev_ulps = (zs.double() - wf.double()).abs() / ulp
+    # (the few elements taken by the second descent -- rows whose fine binades hold too few elements rounded the right way; ~0.1 % -- may
+    # sit up to 1.5 ulp off; everything else is within 1 ulp)
+    assert dev_ulps.max() <= 1.5 + 1e-9 and (dev_ulps > 1.0 + 1e-9).double().mean() <= 2e-3, (float(dev_ulps.max()), float((dev_ulps > 1.0).double().mean()))
     x = torch.randn(64, k, generator=g) + 25.0                   # row mean = 25 sigma
     ref = torch.nn.functional.linear(torch.nn.functional.layer_norm(x, (k,), gamma, beta, 1e-5), w, b)
     rstd = 1.0 / torch.sqrt(x.var(1, unbiased=False, keepdim=True) + 1e-5)

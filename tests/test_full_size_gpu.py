@@ -152,6 +152,17 @@ def test_full_size_f32_mode_meets_the_north_star_tolerance(full):
     assert_north_star(lat2.reshape(ref["lat2"].shape), ref["lat2"], "latents after fused step 2")
 
 
+def _reference_16bit_yardstick(dtype):
+    """The reference's OWN 16-bit mode at full size (16-bit parameters under torch.autocast, test_code/inference.py:246) against
+    its fp32 result -- step 1 of this file's loop on the oracle.  Minutes of CPU time per dtype on the GPU box's host, so the
+    numbers are generated once in the build container (tests/golden/make_autocast_yardstick.py, same weights / inputs / step)
+    and committed as a fixture."""
+    import json
+    import os
+    path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "full_size_autocast_yardstick.json")
+    return json.load(open(path))[str(dtype).replace("torch.", "")]
+
+
 @pytest.mark.parametrize("dtype,rel,cos", [(torch.float16, 4e-3, 0.99999), (torch.bfloat16, 3e-2, 0.9995)])
 @torch.no_grad()
 def test_full_size_two_steps_match_oracle(full, dtype, rel, cos):
@@ -167,6 +178,12 @@ def test_full_size_two_steps_match_oracle(full, dtype, rel, cos):
         print(f"full-size VGL, {dtype}, network contribution to the latents after step {k} vs fp32 oracle: {s}")
         assert s["ref_absmax"] > 0.1, "degenerate comparison"
         assert s["rel_l2"] <= rel and s["cos"] >= cos, (k, s)
+        if k == 1:
+            # yardstick: the reference's own 16-bit mode (autocast oracle) against its fp32 result, same step, same inputs
+            y = _reference_16bit_yardstick(dtype)
+            print(f"full-size VGL, {dtype}, step 1: reference autocast rel-L2 {y['rel_l2']:.3e} (in tol {y['frac_in_tol']:.3f}) | "
+                  f"HIP rel-L2 {s['rel_l2']:.3e} (in tol {s['frac_in_tol']:.3f})")
+            assert s["rel_l2"] <= 1.25 * y["rel_l2"], (s, y)
 
 
 @pytest.mark.parametrize("dtype,fp8", [(torch.float32, False), (torch.bfloat16, False), (torch.bfloat16, True)])
@@ -210,10 +227,51 @@ def test_l0_transformer_block_at_64x112_matches_oracle(dtype, fp8):
         print(f"L0 transformer block at 64x112, {dtype}{' + fp8 attention' if fp8 else ''} vs fp32 oracle: {st}")
         if dtype == torch.float32:
             assert_north_star(got, ref, "L0 transformer block at 64x112 (TT_F32)")
-        else:                                   # measured: bf16 2.2e-3; with e4m3 attention operands the limit is 3e-2
-            assert st["rel_l2"] <= (3e-2 if fp8 else 1e-2) and st["cos"] >= 0.999, st
+        else:                                   # measured 2.2e-3 with bf16 and with e4m3 attention operands alike: limit 2x that
+            assert st["rel_l2"] <= 4.5e-3 and st["cos"] >= 0.9999, st
     finally:
         torch.set_num_threads(threads)
+
+
+@torch.no_grad()
+def test_full_size_config5_step_with_fp8_attention(full):
+    """BASELINE config 5 as a whole: the VGL step at 64x112 latents (14 frames, CFG batch 2, 78 context tokens, the full-size
+    UNet + GestureNet) with ``attention_fp8`` -- the spatial self-attention over 7168 tokens per frame on e4m3 operands with
+    fp8 MFMA, everything else bf16.  Size-independent properties: graph replay == eager launches bit for bit, finite outputs;
+    and a bound against the SAME step with bf16 attention: relative L2 of what the networks contributed to the latents after
+    two steps <= 2.5e-2 (measured 1.64e-2 / 1.20e-2: e4m3 operands have 3 mantissa bits), cosine >= 0.9995.  (The oracle is not run at this size:
+    a 64x112 step takes minutes on the host; the 64x112 block test above and the 32x56 steps compare with it.)"""
+    from this_and_that_vdm_amd.svd.denoise import DenoiseLoop
+    from this_and_that_vdm_amd.svd.scheduling_euler_discrete import EulerDiscreteScheduler
+    from this_and_that_vdm_amd.utils.synthetic import synthetic_inputs
+    unet, cn = _product(full, torch.bfloat16)
+    inp = synthetic_inputs(2, FRAMES, 64, 112, CTX_TOKENS, CTX_DIM, seed=5)
+    sched = EulerDiscreteScheduler()
+    sched.set_timesteps(25)
+    outs = {}
+    try:
+        for fp8, graph in ((True, True), (True, False), (False, True)):
+            unet.attention_fp8 = cn.attention_fp8 = fp8
+            loop = DenoiseLoop(unet, cn, use_graph=graph).begin(**_loop_args(inp, sched.sigmas, sched.timesteps))
+            lats = []
+            for _ in range(2):
+                loop.step()
+                lats.append(loop.result().clone())
+            torch.cuda.synchronize()
+            outs[(fp8, graph)] = lats
+    finally:
+        unet.attention_fp8 = cn.attention_fp8 = False
+    for k in range(2):
+        assert torch.isfinite(outs[(True, True)][k]).all()
+        assert torch.equal(outs[(True, True)][k], outs[(True, False)][k]), "config 5: graph replay must equal eager launches"
+        assert not torch.equal(outs[(True, True)][k], outs[(False, True)][k]), "attention_fp8 had no effect"
+    sample = inp["latents"].double().cuda()
+    for k in range(2):
+        share = float(sched.sigmas[k + 1]) / float(sched.sigmas[0])
+        contrib = lambda z: (z.double().reshape(sample.shape) - sample * share).float().cpu()
+        st = err_stats(contrib(outs[(True, True)][k]), contrib(outs[(False, True)][k]))
+        print(f"config 5 (64x112, fp8 spatial self-attention) vs bf16 attention, network contribution after step {k + 1}: {st}")
+        assert st["ref_absmax"] > 0.1 and st["rel_l2"] <= 2.5e-2 and st["cos"] >= 0.9995, (k, st)
 
 
 @torch.no_grad()

@@ -43,9 +43,33 @@ def test_tiny_models_match_oracle_and_reference_vectors(name, dtype):
 
 
 @pytest.mark.parametrize("dtype", [torch.float16, torch.bfloat16])
+def test_16bit_error_is_the_references_own_16bit_error(dtype):
+    """The yardstick for the 16-bit modes: the reference itself runs in 16 bits under
+    ``torch.autocast`` (test_code/inference.py:246).  Its own distance from the fp32 result -- the oracle with 16-bit parameters
+    under torch.autocast("cpu") vs the fp32 oracle -- is measured on the same inputs, and the HIP path must not be further
+    from the fp32 oracle than 1.25x that (relative L2), output by output.  Both fractions of elements inside
+    rtol 1e-3 / atol 1e-4 are printed: neither 16-bit pipeline meets the tolerance elementwise; TT_F32 does."""
+    if not torch.cuda.is_available():
+        pytest.skip("needs a GPU")
+    from tests.parity_common import autocast_yardstick, build_pair, load_golden
+    g = load_golden("tiny_vgl")
+    _, _, o_unet, o_cn = build_pair("tiny_vgl", dtype, "cuda:0", True)
+    yard = autocast_yardstick(o_unet, o_cn, g, dtype)
+    hip = run_tiny_vgl_parity(dtype, "cuda:0", "tiny_vgl")
+    pairs = [("unet_vl", "unet_vl_vs_oracle"), ("cn_down_worst", "cn_down_worst_vs_oracle"), ("cn_mid", "cn_mid_vs_oracle"),
+             ("unet_vgl", "unet_vgl_vs_oracle")]
+    for yk, hk in pairs:
+        y, h = yard[yk], hip[hk]
+        print(f"{dtype} {yk}: reference autocast rel-L2 {y['rel_l2']:.3e} (in tol {y['frac_in_tol']:.3f}) | "
+              f"HIP rel-L2 {h['rel_l2']:.3e} (in tol {h['frac_in_tol']:.3f})")
+        assert h["rel_l2"] <= 1.25 * y["rel_l2"] + 1e-6, (yk, h, y)
+
+
+@pytest.mark.parametrize("dtype", [torch.float16, torch.bfloat16])
 def test_tiny_model_with_fp8_attention(dtype):
     """BASELINE config 5's attention path switched on (``attention_fp8``): spatial self-attention on e4m3 operands, everything
-    else as before.  Tolerance stated: relative L2 <= 6e-2 against the fp32 oracle (e4m3 has 3 mantissa bits)."""
+    else as before.  Tolerance stated (2x the measured error, so a regression of 2x fails): relative L2 against the fp32 oracle
+    <= 7e-3 with fp16 storage (measured 3.4e-3), <= 2.2e-2 with bf16 storage (measured 1.1e-2); e4m3 has 3 mantissa bits."""
     if not torch.cuda.is_available():
         pytest.skip("needs a GPU")
     from tests.parity_common import build_pair, err_stats, load_golden
@@ -61,7 +85,7 @@ def test_tiny_model_with_fp8_attention(dtype):
     s8, s16 = err_stats(got, ref), err_stats(base, ref)
     print(f"tiny UNet {dtype}: fp8 attention {s8} | 16-bit attention {s16}")
     assert not torch.equal(got, base), "the fp8 path must actually run"
-    assert s8["rel_l2"] <= 6e-2 and s8["cos"] >= 0.998, s8
+    assert s8["rel_l2"] <= (7e-3 if dtype == torch.float16 else 2.2e-2) and s8["cos"] >= 0.9995, s8
 
 
 @pytest.mark.parametrize("dtype", [torch.float16, torch.bfloat16])
@@ -102,8 +126,8 @@ def test_zero_context_shortcut_and_general_path(dtype):
     real = ops.attention
 
     def counting(q, *a, **k):
-        if k.get("mask") == 1:
-            rows.append(q.shape[0])
+        if k.get("mask") in (1, 2):              # every cross-attention launch: spatial (mask 1) and temporal (mask 2; the
+            rows.append(q.shape[0])              # temporal shortcut runs its live residue class as a mask-1 launch)
         return real(q, *a, **k)
 
     with torch.no_grad():
@@ -126,6 +150,8 @@ def test_zero_context_shortcut_and_general_path(dtype):
             rows_nz = sum(rows)
         finally:
             ops.attention = real
+    # with the uncond context all zero exactly half of the cross-attention query rows remain: the cond batch element in the
+    # spatial blocks, the odd pixels (residue class 1 of quirk Q3's pairing) in the temporal blocks
     assert n_short == n_full and 2 * rows_short == rows_full == rows_nz, (n_short, n_full, rows_short, rows_full, rows_nz)
     s_short, s_full, s_2 = err_stats(got_short, ref), err_stats(got_full, ref), err_stats(got2, ref2)
     print(f"{dtype}: shortcut {s_short} | general {s_full} | non-zero uncond context {s_2}")

@@ -278,12 +278,14 @@ def layernorm(x, gamma, beta, eps=1e-5, rowvec=None, rows_per_vec=0, nvec=0):
     return (xs, y) if xs is not None else y
 
 
-def add_rowvec(x, rowvec, rows_per_vec: int, nvec: int):
-    """y[r] = x[r] + rowvec[(r // rows_per_vec) % nvec]  (frame-position embedding, transformer_temporal.py:358-359)."""
+def add_rowvec(x, rowvec, rows_per_vec: int, nvec: int, out=None):
+    """y[r] = x[r] + rowvec[(r // rows_per_vec) % nvec]  (frame-position embedding, transformer_temporal.py:358-359).
+    ``out`` may be ``x`` itself (in place) and both may be strided row views."""
     lib = _lib.load()
     rows, c = x.shape
     assert x.stride(1) == 1 and rowvec.dtype == torch.float32 and rowvec.stride(1) == 1
-    y = torch.empty((rows, c), dtype=x.dtype, device=x.device)
+    y = torch.empty((rows, c), dtype=x.dtype, device=x.device) if out is None else out
+    assert y.shape == x.shape and y.stride(1) == 1 and y.dtype == x.dtype
     check(lib.tt_add_rowvec(_p(x), x.stride(0), rows, c, _p(rowvec), rowvec.stride(0), rows_per_vec, nvec, _p(y), y.stride(0),
                             _code(x.dtype), _stream()), "tt_add_rowvec")
     return y

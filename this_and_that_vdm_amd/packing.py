@@ -46,27 +46,40 @@ def zero_sum_round(w: torch.Tensor, dtype: torch.dtype) -> torch.Tensor:
     (to ~1e-6 of an ulp-sized weight instead of ~sqrt(K) ulps): plain rounding leaves a residual
     r_n = sum_k round(w_nk) != 0 and the fused LayerNorm GEMM would then add  mean(x) * r_n * rstd  to its output -- an error
     that grows with the row mean of x.  Greedy mixed-radix correction, binade by binade from the coarsest spacing to the
-    finest: within a binade every element has the same spacing u, so round(r / u) of them (at most all) are moved by one
-    ulp -- i.e. to their other rounding neighbour -- towards cancelling what is left of the residual r.
+    finest: within a binade every element has the same spacing u, so up to round(r / u) of them are moved by one ulp towards
+    cancelling what is left of the residual r.  The first descent only moves elements whose own rounding error has the sign
+    of the correction: for them the move lands on their OTHER rounding neighbour, so they stay within one ulp of the true
+    value; what that cannot cancel (rare: a row needs more such elements than a binade holds) is handled by a second descent
+    that may take any element (up to 1.5 ulp).  Both stop as soon as every row sums to exactly zero.
     fp32: returned as is (the residual is ~1e-7 of a weight)."""
     if dtype == torch.float32:
         return w.float().contiguous()
     mant, emin = {torch.bfloat16: (7, -126), torch.float16: (10, -14)}[dtype]
+    wd = w.detach().double()
     q = w.detach().to(dtype).double()
+    up = q > wd                                               # rounded up: one ulp DOWN is its other rounding neighbour
+    dn = q < wd
     _, e = torch.frexp(q.abs())                               # |q| = m * 2^e, m in [0.5, 1)
     e = torch.clamp(e - 1, min=emin)                          # binade exponent (subnormals share the lowest one)
     nz = q != 0
     r = q.sum(dim=1)                                          # residual of every row, fp64 (exact: all terms are dyadic)
     lo = int(e[nz].min()) if bool(nz.any()) else 0
     hi = int(e[nz].max()) if bool(nz.any()) else -1
-    for lvl in range(hi, max(lo, hi - 48) - 1, -1):           # <= 49 levels of O(N K) vector work, once per layer at load
-        u = 2.0 ** (lvl - mant)
-        mask = nz & (e == lvl)
-        cnt = mask.sum(dim=1)
-        n = torch.minimum(torch.round(r / u).abs(), cnt.double()) * torch.sign(r)
-        sel = mask & (torch.cumsum(mask, dim=1) <= n.abs()[:, None])
-        q = q - sel.double() * (torch.sign(n) * u)[:, None]
-        r = r - n * u
+    moved = torch.zeros_like(nz)
+    for only_other_neighbour in (True, False):
+        for lvl in range(hi, max(lo, hi - 48) - 1, -1):       # <= 49 levels of O(N K) vector work per descent, once per layer at load
+            if not bool((r != 0).any()):
+                break
+            u = 2.0 ** (lvl - mant)
+            mask = nz & (e == lvl) & ~moved
+            if only_other_neighbour:
+                mask = mask & torch.where((r > 0)[:, None], up, dn)
+            cnt = mask.sum(dim=1)
+            n = torch.minimum(torch.round(r / u).abs(), cnt.double()) * torch.sign(r)
+            sel = mask & (torch.cumsum(mask, dim=1) <= n.abs()[:, None])
+            q = q - sel.double() * (torch.sign(n) * u)[:, None]
+            moved = moved | sel
+            r = r - n * u
     out = q.to(dtype)
     assert torch.equal(out.double(), q), "zero_sum_round: a corrected value is not representable"
     return out.contiguous()

@@ -11,6 +11,7 @@ Activations: 2-D token tensors ``[N*h*w, C]`` (C contiguous) in fp16/bf16 plus a
 from __future__ import annotations
 
 import math
+import os
 from dataclasses import dataclass
 from typing import Dict, List, Optional, Tuple
 
@@ -19,6 +20,9 @@ import torch.nn as nn
 
 from .. import ops
 from ..packing import fold_layernorm, pack_conv1x1, pack_conv3x3, pack_geglu, pack_tconv3, zero_sum_round
+
+
+ZERO_CTX_TEMPORAL = os.environ.get("TT_ZERO_CTX_T", "1") != "0"      # A/B switch of the temporal zero-context shortcut
 
 
 @dataclass
@@ -74,6 +78,18 @@ class StepContext:
         if live[-1] - live[0] + 1 != len(live):
             return None                     # live elements not contiguous in the row order: keep the general path
         return (live[0], len(live))
+
+    def live_classes(self, g: "Geom"):
+        """Temporal cross-attention (reference quirk Q3, transformer_temporal.py:316-319): query pixel p of batch element b sees
+        context (b*hw + p) % CB.  When hw is a multiple of CB that is p % CB = (token row) % CB for every row of the launch: the
+        rows of residue class c all use context c.  Returns None when every context is live (or the classes do not align with
+        the rows): general path.  Otherwise the list of classes whose context is NOT all-zero; the rows of the other classes
+        get exactly 0 from the attention (K = V = 0) and therefore only to_out's bias."""
+        cb = g.ctx_batches
+        if not self.zero_mask or cb < 2 or g.hw % cb or not ZERO_CTX_TEMPORAL:
+            return None
+        live = [c for c in range(cb) if not (self.zero_mask >> c) & 1]
+        return None if len(live) == cb else live
 
     _VT_CACHE: Dict[tuple, torch.Tensor] = {}
 
@@ -512,6 +528,26 @@ class TemporalBasicTransformerBlock(_Packable):
         ops.temporal_attention(qkv, a, batch=g.batch, frames=g.frames, hw=g.hw, heads=self.attn1.heads,
                                head_dim=self.attn1.dim_head)
         t = ops.gemm(a, self.wo1, bias=self.bo1, residual=t)
-        a = _cross_attention(t, self.attn2, self.wq2, self.bq2, self.norm2.eps, self.kv, g, ctx, temporal=True)
-        t = ops.gemm(a, self.wo2, bias=self.bo2, residual=t)
+        live = ctx.live_classes(g)
+        if live is None:
+            a = _cross_attention(t, self.attn2, self.wq2, self.bq2, self.norm2.eps, self.kv, g, ctx, temporal=True)
+            t = ops.gemm(a, self.wo2, bias=self.bo2, residual=t)
+        else:
+            # Rows of a residue class whose context is all zeros (the CFG uncond context: every other pixel, quirk Q3) get
+            # exactly 0 from the cross-attention, i.e. only to_out's bias.  Query projection, attention and output projection
+            # run on the live classes alone, as strided row views t[c::CB] (row stride CB*C; the GEMM and the attention take
+            # row strides, the output projection writes in place over its residual).  Exact.
+            cb, off, cc = g.ctx_batches, self.kv[0], self.kv[1]
+            for cls in range(cb):
+                tv = t[cls::cb]
+                if cls in live:
+                    q = ops.gemm(tv, self.wq2, bias=self.bq2, ln_fold=1, ln_eps=self.norm2.eps)
+                    a = torch.empty_like(q)
+                    # every sequence of this class uses context `cls`: mask 1 with one "batch" spanning all sequences
+                    ops.attention(q, ctx.k_all[:, off:off + cc], ctx.vt_all[off:off + cc], a, nseq=g.n, lq=g.hw // cb,
+                                  heads=self.attn2.heads, head_dim=self.attn2.dim_head, mask=1, lk=ctx.s_ctx, k_seq_stride=ctx.s_pad,
+                                  v_seq_stride=ctx.s_pad, frames=g.n, ctx_batches=cb, batch0=cls)
+                    ops.gemm(a, self.wo2, bias=self.bo2, residual=tv, out=tv)
+                else:
+                    ops.add_rowvec(tv, self.bo2[None, :], rows_per_vec=tv.shape[0], nvec=1, out=tv)
         return self.ff(t, residual=t, blend=x_spatial, alpha=alpha)

@@ -34,7 +34,7 @@ if mode == "serial":
 elif mode.startswith("check:"):              # overlap on, but synchronise + check after the named ops only
     for n in mode[6:].split(","):
         wrap(n)
-unet, cn, _ = bench.build_models("vgl", dtype, torch.device("cuda", 0), 0, 1)
+unet, cn, _, _ = bench.build_models("vgl", dtype, torch.device("cuda", 0), 0, 1)
 loop, args = bench.make_loop(unet, cn, "lo", torch.device("cuda", 0), seed=0)
 loop.use_graph = mode == "graph"
 loop.overlap_branches = mode != "serial"

@@ -6,7 +6,7 @@ import torch
 import bench
 mode, res = (sys.argv[1:] + ["vgl", "lo"])[:2]
 dev = torch.device("cuda", 0)
-unet, cn, _ = bench.build_models(mode, torch.bfloat16, dev, 0, 1)
+unet, cn, _, _ = bench.build_models(mode, torch.bfloat16, dev, 0, 1)
 loop, args = bench.make_loop(unet, cn, res, dev, 0)
 loop.use_graph = False
 loop.overlap_branches = False

@@ -47,6 +47,9 @@ def main():
         except Exception:
             commit = ""
     doc["_measured_at_commit"] = commit or "unknown (no .git on the GPU box: see the committing revision of this file)"
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    import bench
+    doc["_kernel_source_sha16"] = bench.csrc_hash()        # bench.py reports `roofline.traffic` only for the same kernel sources
     json.dump(doc, open(out, "w"), indent=1)
     json.dump(raw, open(raw_out, "w"), indent=1)
     for k, v in traffic.items():

@@ -5,7 +5,7 @@ import sys, time, torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import bench
 dev = torch.device("cuda", 0)
-unet, cn, _ = bench.build_models("vgl", torch.bfloat16, dev, 0, 1)
+unet, cn, _, _ = bench.build_models("vgl", torch.bfloat16, dev, 0, 1)
 from this_and_that_vdm_amd.svd.denoise import DenoiseLoop
 for split in (False, True, False, True):
     loop, args = bench.make_loop(unet, cn, "lo", dev, 0)
