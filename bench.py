@@ -59,7 +59,7 @@ def build_models(mode, dtype, device, rank, world):
             cn = ControlNetModel().to(dtype).eval()
             models.append(("controlnet.", cn))
     from this_and_that_vdm_amd.dist import broadcast_model_, flat_param_buffer
-    bcast_s, checksum = None, 0
+    bcast_s, checksum, prep_s = None, 0, 0.0
     for salt, m in models:
         flat = flat_param_buffer(m)
         if rank == 0:
@@ -71,7 +71,12 @@ def build_models(mode, dtype, device, rank, world):
         # exact integer checksum of the parameter bytes (every rank must hold rank 0's weights after the broadcast)
         bits = flat.view(torch.int16 if flat.element_size() == 2 else torch.int32)
         checksum = (checksum * 1000003 + int(bits.to(torch.int64).sum().item())) % (1 << 61)
-        m.prepare(force=True)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        m.prepare(force=True)                    # weight packing (LayerNorm folds with exact zero row sums, conv re-layouts): once per process
+        torch.cuda.synchronize()
+        prep_s += time.perf_counter() - t0
+    build_models.prepare_s = prep_s
     return unet, cn, bcast_s, checksum
 
 
@@ -413,7 +418,8 @@ def main():
                        "hipgraph": True, "finite_output": finite, "spatial_self_attention": a.attn,
                        "step_tflop_algorithmic": step_tflop,
                        "step_mfma_frac_of_peak": step_tflop / (ms * 1e-3) / peak,
-                       "weight_broadcast_s": bcast_s, "ms_per_step_per_rank": per_rank_ms,
+                       "weight_broadcast_s": bcast_s, "weight_packing_s_per_rank": getattr(build_models, "prepare_s", None),
+                       "ms_per_step_per_rank": per_rank_ms,
                        "weights_identical_on_all_ranks": len(set(checksums)) == 1, "kernel_source_sha16": csrc_hash(), **extras},
             "roofline": roofline, "cpu_baseline": cpu,
         }

@@ -258,6 +258,14 @@ int tt_add_scaled(const void* a, const void* b, float scale, void* y, int64_t n,
 int tt_add_rowvec(const void* x, int64_t ldx, int32_t rows, int32_t c, const float* rowvec, int64_t ld_rowvec,
                   int32_t rows_per_vec, int32_t nvec, void* y, int64_t ldy, int32_t dtype, tt_stream_t stream);
 
+/* y[r, 0:cols] = softmax(x[r, 0:cols]) over fp32 scores, y[r, cols:cols_pad] = 0; y in `dtype` storage.  The attention of the
+ * temporal VAE decoder's mid block (one head of 512 channels over h*w tokens per frame: diffusers
+ * autoencoder_kl_temporal_decoder.py MidBlockTemporalDecoder, reached from
+ * svd/pipeline_stable_video_diffusion_controlnet.py:257-283) runs as  scores = tt_gemm(Q, K, out_f32)  ->  tt_softmax_rows
+ * ->  tt_gemm(P, V^T): head_dim 512 is outside tt_attention's 64 / 128. */
+int tt_softmax_rows(const float* x, int64_t ldx, int32_t rows, int32_t cols, void* y, int64_t ldy, int32_t cols_pad,
+                    int32_t dtype, tt_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

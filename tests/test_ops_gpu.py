@@ -385,6 +385,26 @@ def test_layernorm_and_fused_frame_embedding(ops, dtype, c):
 
 
 @pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("ratio,loose", [(50.0, 1.0), (300.0, 8.0)])
+def test_gemm_fused_layernorm_rows_with_large_row_means(ops, dtype, ratio, loose):
+    """The fused LayerNorm takes 1/sigma from ONE pass over the operand fragments: var = E[x^2] - E[x]^2 in fp32, whose relative
+    error grows like 6e-8 * (1 + mean^2 / var).  Supported range, stated: |row mean| <= 50 sigma keeps the result inside the
+    usual per-kernel tolerance (the hidden states of the transformer blocks stay below ~5 sigma); at 300 sigma (var error
+    ~0.5 %) 8x that tolerance still holds.  Beyond that use tt_layernorm (two-pass) in front of a plain tt_gemm."""
+    from this_and_that_vdm_amd.packing import fold_layernorm, zero_sum_round
+    m, c, n = 700, 320, 256
+    x = (rnd(m, c, dtype=torch.float32, seed=1) + ratio * (1.0 + 0.1 * rnd(m, 1, dtype=torch.float32, seed=9))).to(dtype)
+    w, b = rnd(n, c, dtype=dtype, seed=2, scale=c ** -0.5), rnd(n, dtype=torch.float32, seed=3)
+    g, be = rnd(c, dtype=torch.float32, seed=4, scale=0.2) + 1, rnd(c, dtype=torch.float32, seed=5, scale=0.3)
+    wf, bf = fold_layernorm(w.float(), b, g, be)
+    out = ops.gemm(x.cuda(), zero_sum_round(wf, dtype).cuda(), bias=bf.cuda(), ln_fold=1, ln_eps=1e-5)
+    ref = F.linear(F.layer_norm(x.float(), (c,), g, be, 1e-5), w.float(), b)
+    tol = TOL[dtype]
+    k = 2.0 * loose * (2.0 if dtype == torch.float16 else 1.0)          # (folded weights are rounded after the gamma product)
+    torch.testing.assert_close(out.float().cpu(), ref, rtol=tol["rtol"] * k, atol=tol["atol"] * k)
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
 @pytest.mark.parametrize("m,c,n", [(333, 64, 192), (2500, 320, 960), (9000, 640, 1280), (300, 1280, 2560)])
 def test_gemm_fused_layernorm_rows(ops, dtype, m, c, n):
     """Linear(LayerNorm(x)) with the LayerNorm folded into the GEMM (tt_gemm ln_fold = 1): x reaches the kernel

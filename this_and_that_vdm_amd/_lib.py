@@ -86,6 +86,7 @@ SIGNATURES = {
     "tt_tokens_to_nchw": (C.c_int, [_vp, _i32, _i64, _i32, _i32, _i32, _vp, _i32, _i32, _vp]),
     "tt_add_scaled": (C.c_int, [_vp, _vp, _f32, _vp, _i64, _i32, _vp]),
     "tt_add_rowvec": (C.c_int, [_vp, _i64, _i32, _i32, _vp, _i64, _i32, _i32, _vp, _i64, _i32, _vp]),
+    "tt_softmax_rows": (C.c_int, [_vp, _i64, _i32, _i32, _vp, _i64, _i32, _i32, _vp]),
 }
 
 _lib = None
@@ -117,7 +118,7 @@ def load():
     for name, (res, args) in SIGNATURES.items():
         fn = getattr(lib, name)          # AttributeError here == ABI mismatch with include/ttvdm.h
         fn.restype, fn.argtypes = res, args
-    if lib.tt_abi_version() != 4:
+    if lib.tt_abi_version() != 5:
         raise RuntimeError("libttvdm.so ABI version mismatch")
     _lib = lib
     return lib

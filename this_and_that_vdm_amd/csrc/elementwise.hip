@@ -195,6 +195,46 @@ __global__ void add_rowvec_kernel(const char* x, long ldx, int rows, int cv, con
   }
 }
 
+
+// row softmax of fp32 scores (tt_softmax_rows): one wave per row, the row passes through registers once when it fits
+// (cols <= 64 * 4 * MAXV), otherwise three passes.  Output in the tag's storage type with `pad` zeroed columns behind it.
+template <typename Tag>
+__global__ __launch_bounds__(256) void softmax_rows_kernel(const float* x, long ldx, int rows, int cols, char* y, long ldy, int cols_pad) {
+  const int lane = threadIdx.x & 63;
+  const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (row >= rows) return;
+  const float* xr = x + (long)row * ldx;
+  float mx = -INFINITY;
+  for (int c = lane * 4; c < cols; c += 256) {
+    const float4 v = *(const float4*)(xr + c);
+    mx = fmaxf(fmaxf(mx, c + 0 < cols ? v.x : -INFINITY), fmaxf(c + 1 < cols ? v.y : -INFINITY, fmaxf(c + 2 < cols ? v.z : -INFINITY, c + 3 < cols ? v.w : -INFINITY)));
+  }
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) mx = fmaxf(mx, __shfl_xor(mx, o));
+  float sum = 0.f;
+  for (int c = lane * 4; c < cols; c += 256) {
+    const float4 v = *(const float4*)(xr + c);
+    const float e[4] = {__expf(v.x - mx), __expf(v.y - mx), __expf(v.z - mx), __expf(v.w - mx)};
+#pragma unroll
+    for (int k = 0; k < 4; ++k) if (c + k < cols) sum += e[k];
+  }
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) sum += __shfl_xor(sum, o);
+  const float inv = 1.0f / sum;
+  constexpr int ES = Elem<Tag>::ES;
+  char* yr = y + (long)row * ldy * ES;
+  for (int c = lane * 4; c < cols_pad; c += 256) {
+    float e[4] = {0.f, 0.f, 0.f, 0.f};
+    if (c < cols) {
+      const float4 v = *(const float4*)(xr + c);
+      const float t[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+      for (int k = 0; k < 4; ++k) if (c + k < cols) e[k] = __expf(t[k] - mx) * inv;
+    }
+    *(typename Elem<Tag>::quad_t*)(yr + c * ES) = f32_to_quad<Tag>(e);
+  }
+}
+
 }  // namespace
 
 extern "C" int tt_add_rowvec(const void* x, int64_t ldx, int32_t rows, int32_t c, const float* rowvec, int64_t ld_rowvec,
@@ -210,6 +250,22 @@ extern "C" int tt_add_rowvec(const void* x, int64_t ldx, int32_t rows, int32_t c
   if (dtype == TT_BF16) TT_ARV(bf16_tag); else if (dtype == TT_F16) TT_ARV(f16_tag); else TT_ARV(f32_tag);
 #undef TT_ARV
   TT_CHECK_LAUNCH("tt_add_rowvec");
+  return TT_OK;
+}
+
+
+extern "C" int tt_softmax_rows(const float* x, int64_t ldx, int32_t rows, int32_t cols, void* y, int64_t ldy, int32_t cols_pad,
+                               int32_t dtype, tt_stream_t stream) {
+  if (!x || !y) TT_FAIL(TT_EINVAL, "tt_softmax_rows: null operand");
+  if (rows <= 0 || cols <= 0 || cols_pad < cols || (cols_pad & 3) || (ldx & 3) || ldx < cols_pad || (ldy & 3) || ldy < cols_pad)
+    TT_FAIL(TT_EINVAL, "tt_softmax_rows: cols_pad >= cols, cols_pad / ldx / ldy multiples of 4 and >= cols_pad (rows are read in float4)");
+  if (dtype != TT_BF16 && dtype != TT_F16 && dtype != TT_F32) TT_FAIL(TT_EINVAL, "tt_softmax_rows: bad dtype");
+  hipStream_t st = (hipStream_t)stream;
+  const dim3 grid((rows + 3) / 4), block(256);
+#define TT_SM(TAG) hipLaunchKernelGGL(softmax_rows_kernel<TAG>, grid, block, 0, st, x, (long)ldx, rows, cols, (char*)y, (long)ldy, cols_pad)
+  if (dtype == TT_BF16) TT_SM(bf16_tag); else if (dtype == TT_F16) TT_SM(f16_tag); else TT_SM(f32_tag);
+#undef TT_SM
+  TT_CHECK_LAUNCH("tt_softmax_rows");
   return TT_OK;
 }
 

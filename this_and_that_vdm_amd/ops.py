@@ -291,6 +291,19 @@ def add_rowvec(x, rowvec, rows_per_vec: int, nvec: int, out=None):
     return y
 
 
+def softmax_rows(x, dtype, cols: Optional[int] = None, out=None):
+    """row softmax of fp32 scores x[:, :cols] -> `dtype`, columns cols..out.shape[1] zeroed (padding for a following GEMM)."""
+    lib = _lib.load()
+    assert x.dtype == torch.float32 and x.stride(1) == 1
+    rows = x.shape[0]
+    cols = x.shape[1] if cols is None else cols
+    if out is None:
+        out = torch.empty((rows, (cols + 7) // 8 * 8), dtype=dtype, device=x.device)
+    check(lib.tt_softmax_rows(_p(x), x.stride(0), rows, cols, _p(out), out.stride(0), out.shape[1], _code(dtype), _stream()),
+          "tt_softmax_rows")
+    return out
+
+
 def small_linear(x, w, bias=None, act_in=False, act_out=False, out=None, accumulate=False):
     lib = _lib.load()
     rows, k = x.shape

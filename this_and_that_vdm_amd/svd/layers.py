@@ -191,7 +191,8 @@ class ResnetBlock2D(_Packable):
         self.in_channels, self.out_channels, self.eps = in_channels, out_channels, eps
         self.norm1 = nn.GroupNorm(groups, in_channels, eps=eps)
         self.conv1 = nn.Conv2d(in_channels, out_channels, 3, padding=1)
-        self.time_emb_proj = nn.Linear(temb_channels, out_channels)
+        # temb_channels=None: no FiLM term (the temporal VAE decoder's blocks, diffusers autoencoder_kl_temporal_decoder.py)
+        self.time_emb_proj = nn.Linear(temb_channels, out_channels) if temb_channels is not None else None
         self.norm2 = nn.GroupNorm(groups, out_channels, eps=eps)
         self.conv2 = nn.Conv2d(out_channels, out_channels, 3, padding=1)
         self.conv_shortcut = nn.Conv2d(in_channels, out_channels, 1) if in_channels != out_channels else None
@@ -203,11 +204,13 @@ class ResnetBlock2D(_Packable):
         self.w2, self.b2 = pack_conv3x3(self.conv2.weight.detach().to(dtype)), _f32(self.conv2.bias)
         if self.conv_shortcut is not None:
             self.ws, self.bs = pack_conv1x1(self.conv_shortcut.weight.detach().to(dtype)), _f32(self.conv_shortcut.bias)
-        self.film = reg.add_film(self.time_emb_proj)
+        self.film = reg.add_film(self.time_emb_proj) if self.time_emb_proj is not None else None
 
     def forward(self, x0, x1, g: Geom, ctx: StepContext):
-        off, c = self.film
-        film = g.film(ctx.film, off, c)
+        film = None
+        if self.film is not None:
+            off, c = self.film
+            film = g.film(ctx.film, off, c)
         c0, c1 = x0.shape[1], (x1.shape[1] if x1 is not None else 0)
         # tt_conv3x3 (GroupNorm + SiLU applied while the input patch is staged in LDS, no normalised copy) is opt-in
         # (TT_CONV3X3=1): every column tile re-does the SiLU of its patch, and at 5..10 column tiles per conv that costs more
@@ -222,7 +225,7 @@ class ResnetBlock2D(_Packable):
                                rowvec_rows=g.frames * g.hw)
         else:
             a = ops.groupnorm(x0, x1, g.n, g.hw, 1, self.g1, self.be1, self.eps, True)
-            hmid = ops.gemm(a, self.w1, mode=1, conv=conv, bias=self.b1, rowvec=film, rowvec_rows=g.frames * g.hw)
+            hmid = ops.gemm(a, self.w1, mode=1, conv=conv, bias=self.b1, rowvec=film, rowvec_rows=g.frames * g.hw if film is not None else 0)
         if self.conv_shortcut is not None:
             xs = ops.gemm(x0, self.ws, a1=x1, bias=self.bs)
         else:
@@ -248,7 +251,7 @@ class TemporalResnetBlock(_Packable):
         self.eps = eps
         self.norm1 = nn.GroupNorm(32, in_channels, eps=eps)
         self.conv1 = nn.Conv3d(in_channels, out_channels, (3, 1, 1), padding=(1, 0, 0))
-        self.time_emb_proj = nn.Linear(temb_channels, out_channels)
+        self.time_emb_proj = nn.Linear(temb_channels, out_channels) if temb_channels is not None else None
         self.norm2 = nn.GroupNorm(32, out_channels, eps=eps)
         self.conv2 = nn.Conv3d(out_channels, out_channels, (3, 1, 1), padding=(1, 0, 0))
 
@@ -257,13 +260,13 @@ class TemporalResnetBlock(_Packable):
         self.g2, self.be2 = _f32(self.norm2.weight), _f32(self.norm2.bias)
         self.w1, self.b1 = pack_tconv3(self.conv1.weight.detach().to(dtype)), _f32(self.conv1.bias)
         self.w2, self.b2 = pack_tconv3(self.conv2.weight.detach().to(dtype)), _f32(self.conv2.bias)
-        self.film = reg.add_film(self.time_emb_proj)
+        self.film = reg.add_film(self.time_emb_proj) if self.time_emb_proj is not None else None
 
     def forward(self, s, g: Geom, ctx: StepContext, alpha: float):
-        off, c = self.film
+        film = g.film(ctx.film, *self.film) if self.film is not None else None
         a = _gn(s, None, g, g.frames, self.g1, self.be1, self.eps, True)
-        t = ops.gemm(a, self.w1, mode=2, tconv=(g.frames, g.hw), bias=self.b1, rowvec=g.film(ctx.film, off, c),
-                     rowvec_rows=g.frames * g.hw)
+        t = ops.gemm(a, self.w1, mode=2, tconv=(g.frames, g.hw), bias=self.b1, rowvec=film,
+                     rowvec_rows=g.frames * g.hw if film is not None else 0)
         a = _gn(t, None, g, g.frames, self.g2, self.be2, self.eps, True)
         # x_temporal = s + conv2(...);  out = alpha*s + (1-alpha)*x_temporal
         return ops.gemm(a, self.w2, mode=2, tconv=(g.frames, g.hw), bias=self.b2, residual=s, blend=s, alpha=alpha)
@@ -275,12 +278,16 @@ class AlphaBlender(nn.Module):
 
     def __init__(self, alpha: float, merge_strategy: str = "learned_with_images", switch_spatial_to_temporal_mix: bool = False):
         super().__init__()
-        if merge_strategy != "learned_with_images" or switch_spatial_to_temporal_mix:
+        if merge_strategy not in ("learned_with_images", "learned"):
             raise NotImplementedError(merge_strategy)
+        # "learned" (the temporal VAE decoder) and "learned_with_images" with an all-zero indicator both give sigmoid(mix_factor);
+        # switch_spatial_to_temporal_mix (decoder) blends with 1 - alpha
+        self.switch = bool(switch_spatial_to_temporal_mix)
         self.mix_factor = nn.Parameter(torch.tensor([float(alpha)]))
 
     def alpha_value(self) -> float:
-        return float(torch.sigmoid(self.mix_factor.detach().float()).item())
+        a = float(torch.sigmoid(self.mix_factor.detach().float()).item())
+        return 1.0 - a if self.switch else a
 
 
 class SpatioTemporalResBlock(_Packable):
