@@ -1008,7 +1008,7 @@ void launch(PP& p, int grid_cap, hipStream_t st) {
 
 int main(int argc, char** argv) {
   struct Shape { int m, n, k; };
-  std::vector<Shape> shapes = {{12544, 640, 640}, {12544, 640, 2560}, {3136, 1280, 1280}, {3136, 1280, 5120}, {50176, 640, 320}, {50176, 1280, 320}};
+  std::vector<Shape> shapes = {{8192, 8192, 8192}, {4096, 4096, 4096}, {50176, 2560, 320}, {12544, 5120, 640}, {3136, 10240, 1280}, {12544, 640, 2560}, {12544, 640, 640}, {3136, 1280, 1280}};
   int grid_cap = 256;
   if (argc > 1) grid_cap = atoi(argv[1]);
   hipStream_t st; CK(hipStreamCreate(&st));
