@@ -384,6 +384,55 @@ def test_layernorm_and_fused_frame_embedding(ops, dtype, c):
     close(y2, F.layer_norm(xs.float().cpu(), (c,), g, b, 1e-5), dtype, scale=2.0)      # normalises the STORED sum
 
 
+@pytest.mark.parametrize("dtype", DTYPES16)
+@pytest.mark.parametrize("ln,geglu,m,n,k", [(1, 1, 8192 - 37, 6144 - 16, 128), (1, 0, 8192, 6144 - 48, 192), (0, 1, 8192, 6144, 128),
+                                            (0, 0, 8192 - 200, 6144, 320)])
+def test_gemm_persistent_pingpong_kernel(ops, dtype, ln, geglu, m, n, k):
+    """gemm_pp.hip: tall-and-wide Linear problems without per-row epilogue operands (>= 3 rounds of 256 x 256 tiles per CU) run on
+    the persistent ping-pong kernel -- fused LayerNorm statistics, bias, GEGLU or plain 16-bit output, ragged last tile rows and
+    columns.  Checked against torch fp32 and against the tiled kernel on the same operands (forced tile configuration)."""
+    from this_and_that_vdm_amd.packing import fold_layernorm, pack_geglu, zero_sum_round
+    lib = ops._lib.load()
+    x = (rnd(m, k, dtype=torch.float32, seed=1, scale=1.5) + rnd(m, 1, dtype=torch.float32, seed=9, scale=1.5)).to(dtype)
+    w, b = rnd(n, k, dtype=dtype, seed=2, scale=k ** -0.5), rnd(n, dtype=torch.float32, seed=3)
+    if ln:
+        g, be = rnd(k, dtype=torch.float32, seed=4, scale=0.2) + 1, rnd(k, dtype=torch.float32, seed=5, scale=0.3)
+        wf, bf = fold_layernorm(w.float(), b, g, be)
+        wq = zero_sum_round(wf, dtype)
+        ref = F.linear(F.layer_norm(x.float(), (k,), g, be, 1e-5), w.float(), b)
+    else:
+        wq, bf = w, b
+        ref = F.linear(x.float(), w.float(), b)
+    if geglu:
+        ref = ref[:, :n // 2] * F.gelu(ref[:, n // 2:])
+        wq, bf = pack_geglu(wq, bf)
+    args = dict(bias=bf.cuda(), geglu=bool(geglu), ln_fold=ln, ln_eps=1e-5)
+    xd, wd = x.cuda(), wq.cuda()
+    out = ops.gemm(xd, wd, **args)
+    # (the plan query needs the same TtGemmArgs: go through the profiler hook)
+    ops.PROFILE = []
+    ops.gemm(xd, wd, **args)
+    torch.cuda.synchronize()
+    name = ops.PROFILE[0][0]
+    ops.PROFILE = None
+    assert name.startswith("gemm_pp_kernel<"), name
+    lib.tt_gemm_set_tile_override(11)
+    try:
+        tiled = ops.gemm(xd, wd, **args)
+    finally:
+        lib.tt_gemm_set_tile_override(-1)
+    tol = TOL[dtype]
+    # vs torch: the limits of test_gemm_fused_layernorm_geglu_and_columns (fp16 with folded weights and value * gelu(gate): 5e-3)
+    if dtype == torch.float16 and ln and geglu:
+        rt = at = 5e-3
+    else:
+        k2 = 2.0 if (ln or geglu) else 1.0
+        rt, at = tol["rtol"] * k2, tol["atol"] * k2 * (2.0 if dtype == torch.bfloat16 else 1.0)
+    torch.testing.assert_close(out.float().cpu(), ref, rtol=rt, atol=at)
+    # vs the tiled kernel on the same operands: the same arithmetic up to fp32 summation order / one fused multiply-add
+    torch.testing.assert_close(out.float(), tiled.float(), rtol=tol["rtol"], atol=tol["atol"])
+
+
 @pytest.mark.parametrize("dtype", DTYPES)
 @pytest.mark.parametrize("ratio,loose", [(50.0, 1.0), (300.0, 8.0)])
 def test_gemm_fused_layernorm_rows_with_large_row_means(ops, dtype, ratio, loose):
@@ -592,7 +641,6 @@ def _run_square_320(ops, lib, dtype, m, epi, a, w, bias, res):
     k = n = 320
     g = _lib.TtGemmArgs()
     g.m, g.n, g.k0, g.mode = m, n, k, 0
-    cfg = (C.c_int32 * 7)()
     assert lib.tt_gemm_plan(C.byref(g), cfg) == 0 and cfg[0] == 32 and cfg[1] == 320, list(cfg)
     out = torch.full((m + 8, n), 7.0, dtype=dtype, device="cuda")
     ref = a.float() @ w.float().T

@@ -24,6 +24,8 @@ void launch_f16(GemmP& p, int cfg, hipStream_t st);
 void launch_f32(GemmP& p, int cfg, hipStream_t st);
 void launch_sq320_bf16(const GemmP& p, hipStream_t st);
 void launch_sq320_f16(const GemmP& p, hipStream_t st);
+void launch_pp_bf16(GemmP& p, hipStream_t st);         // gemm_pp.hip: persistent 256 x 256 x 64 ping-pong kernel
+void launch_pp_f16(GemmP& p, hipStream_t st);
 }
 using namespace ttg;
 
@@ -145,6 +147,20 @@ bool sq320_ok(const TtGemmArgs* a) {
          !a->geglu && !a->rowvec && !a->out_f32 && !a->out_col_hw &&
          (!a->blend || (a->blend == a->residual && a->ld_blend == a->ld_res));
 }
+// The persistent big-tile kernel (gemm_pp.hip) takes tall-and-wide Linear problems without per-row epilogue operands when every CU
+// gets several 256 x 256 tiles and the last round of tiles is nearly full: the GEGLU projections at the two finest UNet levels
+// (1960 / 980 tiles).  TT_GEMM_PP=0 keeps them on the tiled kernel (A/B).
+static int g_pp = -1;
+bool pp_ok(const TtGemmArgs* a) {
+  if (g_pp < 0) { const char* e = getenv("TT_GEMM_PP"); g_pp = e ? atoi(e) : 1; }
+  if (!g_pp || forced_cfg() >= 0 || a->dtype == TT_F32 || a->mode != 0 || a->k1 != 0 || a->ln_fold > 1 || a->out_fp8 || a->residual || a->blend ||
+      a->rowvec || a->out_f32 || a->out_col_hw || (a->k0 & 63) || a->k0 < 128 || (a->n & 15) || (a->ldo & 7))
+    return false;
+  const long tiles = (long)ceil_div(a->m, 256) * ceil_div(a->n, 256);
+  const long rounds = (tiles + 255) / 256;
+  return tiles >= 3 * 256 && tiles * 10 >= rounds * 256 * 9;      // >= 3 rounds of tiles per CU, last round >= 90 % full on average
+}
+
 // tile shapes whose fused-LayerNorm variants are built (launch<Tag>() in gemm_kernel.h): the ones the planner picks
 static bool ln_capable(int cfg) { return cfg == 1 || cfg == 2 || cfg == 3 || cfg == 7 || cfg == 9 || cfg == 11 || cfg == 16; }
 static Plan plan_for(const TtGemmArgs* a) {
@@ -163,6 +179,10 @@ static Plan plan_for(const TtGemmArgs* a) {
 
 extern "C" int tt_gemm_plan(const TtGemmArgs* a, int32_t cfg[7]) {
   if (!a || !cfg || a->m <= 0 || a->n <= 0) TT_FAIL(TT_EINVAL, "tt_gemm_plan: bad arguments");
+  if (pp_ok(a)) {             // the persistent ping-pong kernel: stages = 0 marks it (gemm_pp_kernel<dtype, ln, geglu>)
+    cfg[0] = 256; cfg[1] = 256; cfg[2] = 64; cfg[3] = 0; cfg[4] = 2; cfg[5] = 4; cfg[6] = 1;
+    return TT_OK;
+  }
   if (sq320_ok(a)) {          // the streaming kernel for the 320 x 320 linears: 32-row tiles, ring depth 3 (5 without residual)
     cfg[0] = SQ_ROWS; cfg[1] = SQ_N; cfg[2] = SQ_K; cfg[3] = a->residual ? 3 : 5; cfg[4] = 1; cfg[5] = SQ_WAVES; cfg[6] = 1;
     return TT_OK;
@@ -178,6 +198,7 @@ extern "C" int tt_gemm_plan(const TtGemmArgs* a, int32_t cfg[7]) {
 
 extern "C" size_t tt_gemm_ws_bytes(const TtGemmArgs* a) {
   if (!a || a->m <= 0 || a->n <= 0) return 0;
+  if (pp_ok(a)) return 0;
   const Plan pl = plan_for(a);
   return pl.splitk > 1 ? (size_t)pl.splitk * a->m * a->n * sizeof(float) : 0;
 }
@@ -241,6 +262,12 @@ extern "C" int tt_gemm(const TtGemmArgs* a, tt_stream_t stream) {
     p.bias_bytes = p.bias ? (unsigned)p.n * 4u : 0u; p.rowvec_bytes = (unsigned)rvb; p.ws_bytes = 0;
   }
   hipStream_t st = (hipStream_t)stream;
+  if (pp_ok(a)) {
+    p.splitk = 1; p.ws = nullptr; p.ws_bytes = 0; p.group_m_override = group_m_override(); p.group_m = 1;
+    if (a->dtype == TT_BF16) launch_pp_bf16(p, st); else launch_pp_f16(p, st);
+    TT_CHECK_LAUNCH("tt_gemm");
+    return TT_OK;
+  }
   if (sq320_ok(a)) {
     p.splitk = 1; p.ws = nullptr; p.ws_bytes = 0; p.group_m_override = 0; p.group_m = 1;
     if (a->dtype == TT_BF16) launch_sq320_bf16(p, st); else launch_sq320_f16(p, st);
