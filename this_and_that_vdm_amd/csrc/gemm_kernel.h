@@ -77,6 +77,15 @@ template <> __device__ __forceinline__ void ln_stat<f32_tag>(const raw_u32x4_t& 
 #pragma unroll
   for (int d = 0; d < 4; ++d) { const float x = __uint_as_float(w[d]); s += x; q = fmaf(x, x, q); }
 }
+// fp32 storage (TT_F32, the mode that has to meet atol 1e-4 elementwise): sums of x - c with the pivot c = the row's first
+// element, so E[(x-c)^2] - E[x-c]^2 does not cancel when |row mean| >> sigma (unshifted, the fp32 sums cost 6e-5 of the
+// output at 5 sigma and 5e-3 at 50 sigma; shifted ~1e-6 at any mean).  The 16-bit types keep the packed dot products:
+// their storage rounding (1e-3 / 8e-3) covers the one-pass error up to 50 sigma (tests/test_ops_gpu.py).
+__device__ __forceinline__ void ln_stat_shifted(const raw_u32x4_t& f, float c, float& s, float& q) {
+  const unsigned w[4] = {f.x, f.y, f.z, f.w};
+#pragma unroll
+  for (int d = 0; d < 4; ++d) { const float x = __uint_as_float(w[d]) - c; s += x; q = fmaf(x, x, q); }
+}
 
 
 // ---- optional per-block timeline (make timeline): thread 0 of every block stamps the 100 MHz wall clock
@@ -422,13 +431,27 @@ void gemm_kernel(const GemmP p) {
   float ln_s[NLN], ln_q[NLN];
 #pragma unroll
   for (int i = 0; i < NLN; ++i) ln_s[i] = ln_q[i] = 0.f;
+  constexpr bool LN_SHIFT = LN != 0 && std::is_same<Tag, f32_tag>::value;     // see ln_stat_shifted
+  float ln_c[LN_SHIFT ? NLN : 1];
+  if constexpr (LN_SHIFT) {
+#pragma unroll
+    for (int i = 0; i < NLN; ++i) {
+      const int row = LN == 1 ? m0 + a_lds_row[i] : n0 + b_lds_row[i];
+      const bool ok = row < (LN == 1 ? p.m : p.n);
+      ln_c[i] = ok ? *(const float*)((LN == 1 ? p.a0 : p.w) + (long)row * (LN == 1 ? p.lda0 : p.ldw) * 4) : 0.f;
+    }
+  }
   auto mma = [&](const raw_u32x4_t (&af)[FM], const raw_u32x4_t (&bf)[FN]) {
     if constexpr (LN == 1) {
 #pragma unroll
-      for (int i = 0; i < FM; ++i) ln_stat<Tag>(af[i], ln_s[i], ln_q[i]);
+      for (int i = 0; i < FM; ++i) {
+        if constexpr (LN_SHIFT) ln_stat_shifted(af[i], ln_c[i], ln_s[i], ln_q[i]); else ln_stat<Tag>(af[i], ln_s[i], ln_q[i]);
+      }
     } else if constexpr (LN == 2) {
 #pragma unroll
-      for (int j = 0; j < FN; ++j) ln_stat<Tag>(bf[j], ln_s[j], ln_q[j]);
+      for (int j = 0; j < FN; ++j) {
+        if constexpr (LN_SHIFT) ln_stat_shifted(bf[j], ln_c[j], ln_s[j], ln_q[j]); else ln_stat<Tag>(bf[j], ln_s[j], ln_q[j]);
+      }
     }
 #pragma unroll
     for (int i = 0; i < FM; ++i)

@@ -17,7 +17,10 @@
 //     phase, the other reads its fragments and issues DMA, then they swap (s_setprio 1 around the MFMAs);
 //   * the ring keeps streaming across tile boundaries; the tile's bias arrives by a dword LDS-DMA into the wave's strip,
 //     so the kernel has NO register-destination loads and every wait is counted;
-//   * epilogue (both groups together): 1/sigma of the fused LayerNorm from the operand stream as in gemm_kernel.h (KMODE 3),
+//   * the LayerNorm sums of the operand stream (gemm_kernel.h KMODE 3) run in the short read intervals p1 / p3 on the A half still
+//     in registers; in the GEGLU instances each of the four waves of a wave row sums one K step of every slab and the epilogue
+//     adds the four partials through the free half of the strips (tools/pp_scan.py: 2.03 -> 1.73 us per slab; no sums: 1.56);
+//   * epilogue (both groups together): 1/sigma of the fused LayerNorm,
 //     bias, scale, GEGLU (value / gate lane-local, exact-erf GELU), packed to the storage type in the MFMA layout, transposed
 //     through a wave-private 4 KiB strip and stored as 16 bytes per lane (plain: full 128-byte lines).
 #include <stdlib.h>
@@ -37,6 +40,7 @@ __global__ __launch_bounds__(512, 2) void gemm_pp_kernel(const GemmP p) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   constexpr int BM = 256, BN = 256, WTM = 128, WTN = 64, FM = 4, FN = 2, CPR = 8, ES = 2;
   constexpr int REG = 16384, SLOT = 4 * REG, STRIP_OFF = 2 * SLOT;      // regions of a slot: 0 A-lo, 1 A-hi, 2 W-lo, 3 W-hi
+  constexpr bool SPLIT = LNROWS && GEGLU;                               // LayerNorm sums split over the waves of a row (needs the free strip half)
   static_assert(Elem<Tag>::ES == 2, "16-bit storage types only");
   const int tid = threadIdx.x, lane = tid & 63;
   const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -129,9 +133,8 @@ __global__ __launch_bounds__(512, 2) void gemm_pp_kernel(const GemmP p) {
 #pragma unroll
     for (int ks = 0; ks < 4; ++ks) bf[ks] = lds_read16_raw(sbase + (2 + j) * REG + b_addr[ks]);
   };
-  // the 8 MFMAs of quadrant (I2, J); STATS: the LayerNorm sums of the A half that was just read (each element of A passes
-  // through exactly one p0 / p2 per slab), issued behind the MFMAs so the VALU runs under them
-  auto mma = [&](auto i2_tag, auto j_tag, auto stats_tag) {
+  // the 8 MFMAs of quadrant (I2, J)
+  auto mma = [&](auto i2_tag, auto j_tag) {
     constexpr int I2 = decltype(i2_tag)::value, J = decltype(j_tag)::value;
     __builtin_amdgcn_s_setprio(1);
 #pragma unroll
@@ -141,17 +144,27 @@ __global__ __launch_bounds__(512, 2) void gemm_pp_kernel(const GemmP p) {
         acc[I2 * 2 + i][J] = Cvt<Tag>::mfma32(make_uint4(bf[ks].x, bf[ks].y, bf[ks].z, bf[ks].w),
                                               make_uint4(af[i][ks].x, af[i][ks].y, af[i][ks].z, af[i][ks].w), acc[I2 * 2 + i][J]);
     __builtin_amdgcn_s_setprio(0);
-    if constexpr (LNROWS && decltype(stats_tag)::value) {
+  };
+  // LayerNorm sums of the A half in the fragment registers (each element of A passes through exactly one p0 / p2 per slab).  They
+  // run in the READ interval of the FOLLOWING phase (p1 / p3: only W fragments to read, the A half still in registers), under
+  // the latency of those reads: that is when the other group's wave on this SIMD issues its 8 MFMAs, so the two pipes overlap.
+  // Behind the wave's own MFMAs they lengthen its MFMA interval while the other group waits at the barrier (+0.45 us per slab);
+  // in the read interval of p0 / p2 they sit on top of the longest read bursts (+0.2 us per slab).  The four waves of a wave row hold the SAME A fragments:
+  // with SPLIT each sums only K step ks == wc and the epilogue adds the four partial sums.
+  auto stats = [&](auto i2_tag) {
+    constexpr int I2 = decltype(i2_tag)::value;
+    if constexpr (LNROWS) {
 #pragma unroll
-      for (int i = 0; i < 2; ++i)
+      for (int ks = 0; ks < 4; ++ks)
+        if (!SPLIT || ks == wc) {
 #pragma unroll
-        for (int ks = 0; ks < 4; ++ks) ln_stat<Tag>(af[i][ks], ln_s[I2 * 2 + i], ln_q[I2 * 2 + i]);
-      __builtin_amdgcn_sched_barrier(0);       // the sums read raw-asm fragment registers: keep them in front of the next read
+          for (int i = 0; i < 2; ++i) ln_stat<Tag>(af[i][ks], ln_s[I2 * 2 + i], ln_q[I2 * 2 + i]);
+        }
+      __builtin_amdgcn_sched_barrier(0);       // the sums read raw-asm fragment registers: keep them between the wait and the barrier
     }
   };
   auto bar = [&]() { __builtin_amdgcn_s_barrier(); asm volatile("" ::: "memory"); };
   using I0 = std::integral_constant<int, 0>; using I1 = std::integral_constant<int, 1>;
-  using ST = std::true_type; using NS = std::false_type;
 
   // ---- prologue: slab 0 (slot 0) complete + A-lo, W-hi, A-hi of slab 1 (slot 1), as the steady state would have issued them
   // (W-lo closes a slab: it advances the producer cursor, so it goes last)
@@ -169,6 +182,7 @@ __global__ __launch_bounds__(512, 2) void gemm_pp_kernel(const GemmP p) {
     int m0, n0;
     tile_of(c_it, m0, n0);
     ++c_it;
+
     __builtin_amdgcn_sched_barrier(0);
     asm volatile("s_nop 15\n\ts_nop 15" ::: "memory");      // MFMA results -> VALU / raw ds_write: no hazard recogniser in asm
     // bias of this lane's columns: the DMA put the wave's 64 values (columns wc*64 ..) at the start of the strip.  In the MFMA
@@ -186,6 +200,26 @@ __global__ __launch_bounds__(512, 2) void gemm_pp_kernel(const GemmP p) {
 #pragma unroll
         for (int g = 0; g < 4; ++g)
           b4[j][g] = make_float4(__uint_as_float(t[j][g].x), __uint_as_float(t[j][g].y), __uint_as_float(t[j][g].z), __uint_as_float(t[j][g].w));
+    }
+    if constexpr (SPLIT) {
+      // partial sums of this wave (its K steps, its half of each K step) -> upper half of its strip, 32 bytes per lane; after the
+      // barrier every wave adds the four partials of its wave row (strips wr*4 + 0..3) for its own half; the halves meet below
+      lds_write16_raw(strip + 2048 + lane * 32, ln_s[0], ln_q[0], ln_s[1], ln_q[1]);
+      lds_write16_raw(strip + 2048 + lane * 32 + 16, ln_s[2], ln_q[2], ln_s[3], ln_q[3]);
+      lds_wait<0>();
+      bar();
+      raw_u32x4_t t[4][2];
+      const unsigned row_strips = lds_base + STRIP_OFF + wr * 4 * 4096 + 2048 + lane * 32;
+#pragma unroll
+      for (int c = 0; c < 4; ++c) { t[c][0] = lds_read16_raw(row_strips + c * 4096); t[c][1] = lds_read16_raw(row_strips + c * 4096 + 16); }
+      lds_wait<0>();
+#pragma unroll
+      for (int h = 0; h < 2; ++h) {
+        ln_s[2 * h] = (__uint_as_float(t[0][h].x) + __uint_as_float(t[1][h].x)) + (__uint_as_float(t[2][h].x) + __uint_as_float(t[3][h].x));
+        ln_q[2 * h] = (__uint_as_float(t[0][h].y) + __uint_as_float(t[1][h].y)) + (__uint_as_float(t[2][h].y) + __uint_as_float(t[3][h].y));
+        ln_s[2 * h + 1] = (__uint_as_float(t[0][h].z) + __uint_as_float(t[1][h].z)) + (__uint_as_float(t[2][h].z) + __uint_as_float(t[3][h].z));
+        ln_q[2 * h + 1] = (__uint_as_float(t[0][h].w) + __uint_as_float(t[1][h].w)) + (__uint_as_float(t[2][h].w) + __uint_as_float(t[3][h].w));
+      }
     }
     float rs[FM];
 #pragma unroll
@@ -277,29 +311,34 @@ __global__ __launch_bounds__(512, 2) void gemm_pp_kernel(const GemmP p) {
     stage(slot ^ 1, R2{});
     lds_wait<0>();
     bar();
-    mma(I0{}, I0{}, ST{});
+    mma(I0{}, I0{});
     bar();
     // ---- p1 (0,1): W-hi ; DMA: A-lo of slab s+2 (this slot; released in p0)
     read_b(sb, 1);
     stage(slot, R0{});
+    stats(I0{});
     lds_wait<0>();
     bar();
-    mma(I0{}, I1{}, NS{});
+    mma(I0{}, I1{});
     bar();
     // ---- p2 (1,1): A-hi ; DMA: W-hi of slab s+2 (released in p1)
     read_a(sb, 1);
     stage(slot, R3{});
     lds_wait<0>();
     bar();
-    mma(I1{}, I1{}, ST{});
+    mma(I1{}, I1{});
     bar();
     // ---- p3 (1,0): W-lo again ; DMA: A-hi of slab s+2 (released in p2) ; everything up to W-lo of slab s+1 has landed
+    // (vmcnt counts the epilogue's stores too, in issue order.  Issuing W-lo before the epilogue and letting the stores stay in
+    // flight for one more slab -- vmcnt(7 + stores) in a tile's first slab -- measured no gain: the write burst of 256 CUs
+    // finishing their tiles together costs ~2 us per tile wherever the wave meets it.)
     read_b(sb, 0);
     stage(slot, R1{});
+    stats(I1{});
     pp_wait_vm<6>();
     lds_wait<0>();
     bar();
-    mma(I1{}, I0{}, NS{});
+    mma(I1{}, I0{});
     bar();
     if (++c_ks == KS) {
       c_ks = 0;
