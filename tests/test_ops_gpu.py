@@ -386,7 +386,9 @@ def test_layernorm_and_fused_frame_embedding(ops, dtype, c):
 
 @pytest.mark.parametrize("dtype", DTYPES16)
 @pytest.mark.parametrize("ln,geglu,m,n,k", [(1, 1, 8192 - 37, 6144 - 16, 128), (1, 0, 8192, 6144 - 48, 192), (0, 1, 8192, 6144, 128),
-                                            (0, 0, 8192 - 200, 6144, 320)])
+                                            (0, 0, 8192 - 200, 6144, 320),
+                                            (1, 1, 3136, 10240, 1280),      # 12 whole tile rows + a ragged row of 64: ragged tiles last, to the idle CUs
+                                            (0, 0, 3072 + 130, 10240, 256)])  # ragged row of 130 rows: the upper wave row works, the lower skips
 def test_gemm_persistent_pingpong_kernel(ops, dtype, ln, geglu, m, n, k):
     """gemm_pp.hip: tall-and-wide Linear problems without per-row epilogue operands (>= 3 rounds of 256 x 256 tiles per CU) run on
     the persistent ping-pong kernel -- fused LayerNorm statistics, bias, GEGLU or plain 16-bit output, ragged last tile rows and

@@ -148,8 +148,12 @@ bool sq320_ok(const TtGemmArgs* a) {
          (!a->blend || (a->blend == a->residual && a->ld_blend == a->ld_res));
 }
 // The persistent big-tile kernel (gemm_pp.hip) takes tall-and-wide Linear problems without per-row epilogue operands when every CU
-// gets several 256 x 256 tiles and the last round of tiles is nearly full: the GEGLU projections at the two finest UNet levels
-// (1960 / 980 tiles).  TT_GEMM_PP=0 keeps them on the tiled kernel (A/B).
+// gets about two or more 256 x 256 tiles and the last round of tiles is nearly full: the GEGLU projections at the three finest UNet
+// levels (1960 / 980 / 480 tiles).  A problem whose row count is not a multiple of 256 and that only qualifies without its
+// ragged last tile row is launched in two parts -- whole tile rows on the persistent kernel, the remaining < 256 rows on the tiled
+// kernel (3136 rows: 480 tiles = 1.9 rounds + 64 rows, instead of 520 tiles = 3 rounds; a ragged tile costs the persistent kernel
+// a whole tile time even with its all-zero MFMAs skipped, and cutting tiles along K stream-K fashion costs more in partial-tile
+// traffic than it saves: DESIGN.md section 6.0).  TT_GEMM_PP=0 keeps everything on the tiled kernels (A/B).
 static int g_pp = -1;
 bool pp_ok(const TtGemmArgs* a) {
   if (g_pp < 0) { const char* e = getenv("TT_GEMM_PP"); g_pp = e ? atoi(e) : 1; }
@@ -158,7 +162,22 @@ bool pp_ok(const TtGemmArgs* a) {
     return false;
   const long tiles = (long)ceil_div(a->m, 256) * ceil_div(a->n, 256);
   const long rounds = (tiles + 255) / 256;
-  return tiles >= 3 * 256 && tiles * 10 >= rounds * 256 * 9;      // >= 3 rounds of tiles per CU, last round >= 90 % full on average
+  return tiles >= 460 && tiles * 10 >= rounds * 256 * 9;      // ~2 rounds of tiles per CU or more, last round >= 90 % full on average
+}
+// rows the persistent kernel takes when the problem is launched in two parts (0: one launch)
+static int pp_split_rows(const TtGemmArgs* a) {
+  if ((a->m & 255) == 0 || a->m < 512 || pp_ok(a)) return 0;
+  TtGemmArgs head = *a;
+  head.m = a->m & ~255;
+  return pp_ok(&head) ? head.m : 0;
+}
+static void pp_split(const TtGemmArgs* a, int rows, TtGemmArgs* head, TtGemmArgs* tail) {
+  const size_t es = 2;                                      // 16-bit storage (pp_ok)
+  *head = *a; *tail = *a;
+  head->m = rows;
+  tail->m = a->m - rows;
+  tail->a0 = (const char*)a->a0 + (size_t)rows * a->lda0 * es;
+  tail->out = (char*)a->out + (size_t)rows * a->ldo * es;
 }
 
 // tile shapes whose fused-LayerNorm variants are built (launch<Tag>() in gemm_kernel.h): the ones the planner picks
@@ -179,7 +198,7 @@ static Plan plan_for(const TtGemmArgs* a) {
 
 extern "C" int tt_gemm_plan(const TtGemmArgs* a, int32_t cfg[7]) {
   if (!a || !cfg || a->m <= 0 || a->n <= 0) TT_FAIL(TT_EINVAL, "tt_gemm_plan: bad arguments");
-  if (pp_ok(a)) {             // the persistent ping-pong kernel: stages = 0 marks it (gemm_pp_kernel<dtype, ln, geglu>)
+  if (pp_ok(a) || pp_split_rows(a)) {             // the persistent ping-pong kernel (all or all but the last < 256 rows): stages = 0 marks it (gemm_pp_kernel<dtype, ln, geglu>)
     cfg[0] = 256; cfg[1] = 256; cfg[2] = 64; cfg[3] = 0; cfg[4] = 2; cfg[5] = 4; cfg[6] = 1;
     return TT_OK;
   }
@@ -199,6 +218,7 @@ extern "C" int tt_gemm_plan(const TtGemmArgs* a, int32_t cfg[7]) {
 extern "C" size_t tt_gemm_ws_bytes(const TtGemmArgs* a) {
   if (!a || a->m <= 0 || a->n <= 0) return 0;
   if (pp_ok(a)) return 0;
+  if (const int rows = pp_split_rows(a)) { TtGemmArgs head, tail; pp_split(a, rows, &head, &tail); return tt_gemm_ws_bytes(&tail); }
   const Plan pl = plan_for(a);
   return pl.splitk > 1 ? (size_t)pl.splitk * a->m * a->n * sizeof(float) : 0;
 }
@@ -211,6 +231,12 @@ extern "C" int tt_gemm(const TtGemmArgs* a, tt_stream_t stream) {
   if ((a->lda0 & 7) || (a->k1 && (a->lda1 & 7)) || (a->ldw & 7)) TT_FAIL(TT_EINVAL, "tt_gemm: row strides must be multiples of 8 elements");
   if (a->k1 && !a->a1) TT_FAIL(TT_EINVAL, "tt_gemm: k1 > 0 without a1");
   if (a->mode < 0 || a->mode > 2) TT_FAIL(TT_EINVAL, "tt_gemm: bad mode %d", a->mode);
+  if (const int rows = pp_split_rows(a)) {                  // whole tile rows -> persistent kernel, the ragged rest -> tiled kernel
+    TtGemmArgs head, tail;
+    pp_split(a, rows, &head, &tail);
+    const int rc = tt_gemm(&head, stream);
+    return rc != TT_OK ? rc : tt_gemm(&tail, stream);
+  }
   if (a->geglu && ((a->n & 15) || a->residual || a->blend || a->rowvec || a->out_f32 || a->out_col_hw))
     TT_FAIL(TT_EINVAL, "tt_gemm: geglu needs n %% 16 == 0 and no other epilogue terms");
   if (a->rowvec && a->rowvec_rows <= 0) TT_FAIL(TT_EINVAL, "tt_gemm: rowvec_rows");
