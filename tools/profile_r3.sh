@@ -5,6 +5,7 @@ set -u
 mkdir -p gpurun_out/profiles
 P=gpurun_out/profiles
 tools/profile_round.sh r3_vgl_lo_bf16 lo
+cp gpurun_out/profiles/r3_hbm_traffic.json profiles/      # bench.py reads the traffic of the dominant kernel from the tracked copy
 b() { python bench.py "$@" 2>/dev/null | tail -1; }
 b > $P/r3_bench_lo.json
 b --mode vl --no-cpu-baseline > $P/r3_bench_vl.json
