@@ -48,3 +48,34 @@ def test_ops_refuse_cpu_tensors(lib):
     from this_and_that_vdm_amd import ops
     with pytest.raises(RuntimeError, match="no CPU fallback"):
         ops.gemm(torch.zeros(8, 16, dtype=torch.float16), torch.zeros(8, 16, dtype=torch.float16))
+
+
+def test_gemm_dispatch_rules_of_the_persistent_kernel(lib):
+    """tt_gemm_plan is host-only: which problems go to gemm_pp_kernel (reported as stages = 0, tile 256 x 256 x 64).
+    The GEGLU projections of the three finest levels do (the 8 x 14 one through its 12 whole tile rows); anything with a per-row
+    epilogue operand, fp32 storage, a conv mode, too few tiles or a poorly filled last round stays on the tiled kernels."""
+    import ctypes as C
+
+    def plan(m, n, k, dtype, **kw):
+        g = _lib.TtGemmArgs()
+        g.m, g.n, g.k0, g.mode, g.dtype = m, n, k, 0, dtype
+        g.lda0, g.ldw, g.ldo = k, k, n
+        g.ln_eps = 1e-5
+        for name, v in kw.items():
+            setattr(g, name, v)
+        cfg = (C.c_int32 * 7)()
+        assert lib.tt_gemm_plan(C.byref(g), cfg) == 0
+        return list(cfg), lib.tt_gemm_ws_bytes(C.byref(g))
+
+    from this_and_that_vdm_amd import ops
+    bf16, f32 = ops.TT_BF16, ops.TT_F32
+    pp = [256, 256, 64, 0]
+    for m, n, k in ((50176, 2560, 320), (12544, 5120, 640), (3136, 10240, 1280), (200704, 2560, 320)):
+        cfg, ws = plan(m, n, k, bf16, ln_fold=1, geglu=1)
+        assert cfg[:4] == pp and ws == 0, (m, n, k, cfg)
+    assert plan(3072, 10240, 1280, bf16)[0][:4] == pp                      # 480 tiles: 1.9 rounds, 94 % full
+    assert plan(50176, 960, 320, bf16, ln_fold=1)[0][:4] != pp             # 784 tiles: 4 rounds at 77 %
+    assert plan(784, 10240, 1280, bf16, ln_fold=1, geglu=1)[0][:4] != pp   # 160 tiles
+    assert plan(50176, 2560, 320, f32)[0][:4] != pp                        # fp32 storage
+    assert plan(50176, 2560, 320, bf16, residual=1)[0][:4] != pp           # per-row epilogue operand (any non-null pointer)
+    assert plan(50176, 2560, 328, bf16)[0][:4] != pp                       # K not a multiple of 64
