@@ -195,10 +195,13 @@ int tt_groupnorm_apply(const void* x0, int32_t c0, const void* x1, int32_t c1, i
                        const float* scale, const float* shift, int32_t silu, void* y, int64_t ldy,
                        int32_t dtype, tt_stream_t stream);
 
-/* Statistics + apply in ONE launch for per-image GroupNorm (frames_per_group = 1) of small images (at most 640 KiB per image:
- * the 16x28 / 8x14 / 4x7 levels at 256x448): y = act(group_norm(x0 | x1)), no workspace, no scale/shift arrays.  Same result as
- * tt_groupnorm_stats + tt_groupnorm_apply up to fp32 summation order.  ResnetBlock2D norm1 / norm2 (diffusers resnet.py),
- * TransformerSpatioTemporalModel.norm (transformer_temporal.py:323), conv_norm_out (unet...:526). */
+/* Statistics + apply in ONE launch for per-image GroupNorm (frames_per_group = 1): y = act(group_norm(x0 | x1)), no workspace, no
+ * scale/shift arrays.  Images of >= 256 rows: one block per (image, slice of consecutive groups) -- a group's statistics need only
+ * its own channels, so blocks never exchange anything and x is read from HBM once (the apply pass re-reads the slice from L2).
+ * Smaller images (at most 640 KiB per image: the 8x14 / 4x7 levels at 256x448): one block per image and row part, each recomputing
+ * the image's statistics.  Same result as tt_groupnorm_stats + tt_groupnorm_apply up to fp32 summation order; bit-reproducible.
+ * ResnetBlock2D norm1 / norm2 (diffusers resnet.py), TransformerSpatioTemporalModel.norm (transformer_temporal.py:323),
+ * conv_norm_out (unet...:526). */
 int tt_groupnorm_small_supported(int32_t hw, int32_t c, int32_t dtype);
 int tt_groupnorm_small(const void* x0, int32_t c0, const void* x1, int32_t c1, int32_t nimg, int32_t hw,
                        const float* gamma, const float* beta, float eps, int32_t silu, void* y, int64_t ldy,

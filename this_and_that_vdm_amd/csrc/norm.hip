@@ -306,6 +306,132 @@ __global__ __launch_bounds__(256) void ln_kernel(const char* x, long ldx, int ro
   }
 }
 
+
+// ---- per-image GroupNorm of ANY size in one launch, without any exchange between blocks: the statistics of a group need only
+// that group's channels, so block (image, slice) owns `gpb` consecutive groups = `nv` 8-channel vectors of every row: it sums
+// them (fp32 per thread and channel, fp64 per group in a fixed order: bit-reproducible), then re-reads its slice -- still in L2 --
+// normalises, activates and stores it.  x crosses HBM once in each direction; statistics, finalize and apply are one launch.
+// The slices of one image go to ONE XCD (linear block L: XCD L % 8 runs images L % 8 + 8 k), whose L2 then serves the sectors
+// that neighbouring slices share (a 10-channel group is 20 bytes: slices are not sector-aligned).
+template <typename Tag>
+__global__ __launch_bounds__(512) void gn_group_kernel(const char* x0, int c0, const char* x1, int c1, int nimg, int hw, int gpb, int nslices,
+                                                       int rlanes, const float* gamma, const float* beta, float eps, int silu,
+                                                       char* y, long ldy) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  __shared__ float s_mean[GN_GROUPS], s_rstd[GN_GROUPS];
+  const int C = c0 + c1, cpg = C / GN_GROUPS;
+  const int L = blockIdx.x, xcd = L & 7, t = L >> 3;
+  const int slice = t % nslices, img = xcd + 8 * (t / nslices);
+  if (img >= nimg) return;
+  const int nch = gpb * cpg, nv = nch >> 3, ch_lo = slice * nch;
+  const int tid = threadIdx.x;
+  const int myv = tid % nv, myr = tid / nv;                 // vector of the slice, row lane
+  float* psum = (float*)smem;                               // [rlanes][nch]
+  float* psq = psum + rlanes * nch;
+  constexpr int ES = Elem<Tag>::ES;
+  const int ch = ch_lo + myv * 8;
+  const char* base; long ld; int coff;
+  if (ch < c0) { base = x0; ld = c0; coff = ch; } else { base = x1; ld = c1; coff = ch - c0; }
+  const char* pbase = base + (((long)img * hw) * ld + coff) * ES;
+  const long rstride = ld * ES;
+  if (myr < rlanes) {
+    float s[8], q[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) s[e] = q[e] = 0.f;
+    int r = myr;
+    for (; r + 7 * rlanes < hw; r += 8 * rlanes) {
+      float f[8][8];
+#pragma unroll
+      for (int k = 0; k < 8; ++k) load8<Tag>(pbase + (long)(r + k * rlanes) * rstride, f[k]);
+#pragma unroll
+      for (int k = 0; k < 8; ++k) {
+#pragma unroll
+        for (int e = 0; e < 8; ++e) { s[e] += f[k][e]; q[e] = fmaf(f[k][e], f[k][e], q[e]); }
+      }
+    }
+    for (; r < hw; r += rlanes) {
+      float f[8];
+      load8<Tag>(pbase + (long)r * rstride, f);
+#pragma unroll
+      for (int e = 0; e < 8; ++e) { s[e] += f[e]; q[e] = fmaf(f[e], f[e], q[e]); }
+    }
+#pragma unroll
+    for (int e = 0; e < 8; ++e) { psum[myr * nch + myv * 8 + e] = s[e]; psq[myr * nch + myv * 8 + e] = q[e]; }
+  }
+  __syncthreads();
+  {
+    // group g of the slice <- 32 lanes (slices of its rlanes * cpg partial sums), combined by a fixed-order xor tree
+    const int g = tid >> 5, sl = tid & 31;
+    if (g < gpb) {
+      double a = 0.0, b = 0.0;
+      const int n = rlanes * cpg;
+      for (int i = sl; i < n; i += 32) {
+        const int r = i / cpg, c = g * cpg + (i - r * cpg);
+        a += (double)psum[r * nch + c]; b += (double)psq[r * nch + c];
+      }
+#pragma unroll
+      for (int o = 16; o > 0; o >>= 1) { a += __shfl_xor(a, o); b += __shfl_xor(b, o); }
+      if (sl == 0) {
+        const double cnt = (double)hw * cpg;
+        const double mean = a / cnt;
+        double var = b / cnt - mean * mean;
+        if (var < 0.0) var = 0.0;
+        s_mean[g] = (float)mean;
+        s_rstd[g] = (float)(1.0 / sqrt(var + (double)eps));
+      }
+    }
+  }
+  __syncthreads();
+  if (myr < rlanes) {
+    float sc[8], sh[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      const int gg = (myv * 8 + e) / cpg;
+      sc[e] = s_rstd[gg] * gamma[ch + e];
+      sh[e] = beta[ch + e] - s_mean[gg] * sc[e];
+    }
+    char* ybase = y + (((long)img * hw) * ldy + ch) * ES;
+    const long ystride = ldy * ES;
+    int r = myr;
+    for (; r + 3 * rlanes < hw; r += 4 * rlanes) {
+      float f[4][8];
+#pragma unroll
+      for (int k = 0; k < 4; ++k) load8<Tag>(pbase + (long)(r + k * rlanes) * rstride, f[k]);
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+          const float v = fmaf(f[k][e], sc[e], sh[e]);
+          f[k][e] = silu ? silu_f(v) : v;
+        }
+        store8<Tag>(ybase + (long)(r + k * rlanes) * ystride, f[k]);
+      }
+    }
+    for (; r < hw; r += rlanes) {
+      float f[8];
+      load8<Tag>(pbase + (long)r * rstride, f);
+#pragma unroll
+      for (int e = 0; e < 8; ++e) {
+        const float v = fmaf(f[e], sc[e], sh[e]);
+        f[e] = silu ? silu_f(v) : v;
+      }
+      store8<Tag>(ybase + (long)r * ystride, f);
+    }
+  }
+}
+// groups per block: the smallest count whose channels fill whole 8-channel vectors, doubled while a row's slice is below 128 bytes
+// and the launch keeps >= 256 blocks.  0: the channel counts do not allow it (a source boundary inside a vector cannot happen:
+// c0 is a multiple of 8)
+static int gn_group_gpb(int nimg, int C, int es) {
+  const int cpg = C / GN_GROUPS;
+  int gpb = 1;
+  while ((gpb * cpg) & 7) gpb *= 2;                          // <= 8
+  if (gpb > GN_GROUPS) return 0;
+  while (gpb * 2 <= 16 && gpb * cpg * es < 128 && (long)(GN_GROUPS / (gpb * 2)) * nimg >= 256) gpb *= 2;
+  if ((gpb * cpg) >> 3 > 512) return 0;                      // one thread per vector at least
+  return gpb;
+}
+
 // the per-image kernel keeps [rpb][C] x 2 fp32 partials in dynamic LDS (at most 96 KiB): ONE opt-in (per device) with that maximum
 constexpr int GN_IMAGE_LDS_MAX = 96 * 1024;
 template <typename Tag> static void gn_image_opt_in() {
@@ -373,9 +499,19 @@ static int gn_small_rpb(int C, int hw) {
   if (rpb > hw) rpb = hw;
   return rpb;
 }
+// images of fewer rows keep the one-block-per-image kernel (measured: 112 x 2560 41 us grouped vs 26 us, 28 x 2560 23 vs 11 -- the
+// per-group combination of the row lanes' sums dominates a block that owns three rows per lane)
+constexpr int GN_GROUPED_MIN_ROWS = 256;
+static int g_gn_grouped = -1;          // TT_GN_GROUPED=0: the round-2 routes (A/B)
+static bool gn_grouped_on() {
+  if (g_gn_grouped < 0) { const char* e = getenv("TT_GN_GROUPED"); g_gn_grouped = e ? atoi(e) : 1; }
+  return g_gn_grouped != 0;
+}
 extern "C" int tt_groupnorm_small_supported(int32_t hw, int32_t c, int32_t dtype) {
   const int es = dtype == TT_F32 ? 4 : 2;
-  return hw > 0 && c > 0 && (c % GN_GROUPS) == 0 && (c >> 3) <= 1024 && (long)hw * c * es <= GN_ONE_BYTES;
+  if (hw <= 0 || c <= 0 || (c % GN_GROUPS) || (c & 7)) return 0;
+  if (gn_grouped_on() && hw >= GN_GROUPED_MIN_ROWS && gn_group_gpb(1, c, es) > 0) return 1;     // one block per (image, group slice)
+  return (c >> 3) <= 1024 && (long)hw * c * es <= GN_ONE_BYTES;
 }
 extern "C" int tt_groupnorm_small(const void* x0, int32_t c0, const void* x1, int32_t c1, int32_t nimg, int32_t hw,
                                   const float* gamma, const float* beta, float eps, int32_t silu, void* y, int64_t ldy,
@@ -387,12 +523,26 @@ extern "C" int tt_groupnorm_small(const void* x0, int32_t c0, const void* x1, in
   if (dtype != TT_BF16 && dtype != TT_F16 && dtype != TT_F32) TT_FAIL(TT_EINVAL, "tt_groupnorm_small: bad dtype");
   if (!tt_groupnorm_small_supported(hw, C, dtype))
     TT_FAIL(TT_EUNSUPPORTED, "tt_groupnorm_small: %d x %d per image is served by tt_groupnorm_stats + tt_groupnorm_apply", hw, C);
+  hipStream_t st = (hipStream_t)stream;
+  const int es = dtype == TT_F32 ? 4 : 2;
+  if (const int gpb = gn_grouped_on() && hw >= GN_GROUPED_MIN_ROWS ? gn_group_gpb(nimg, C, es) : 0) {
+    const int nslices = GN_GROUPS / gpb, nv = (gpb * (C / GN_GROUPS)) >> 3;
+    int rlanes = 512 / nv;
+    if (rlanes > hw) rlanes = hw;
+    const size_t ldsg = (size_t)2 * rlanes * nv * 8 * sizeof(float);
+    const int blocks = ((nimg + 7) / 8) * 8 * nslices;
+#define TT_GNG(TAG) hipLaunchKernelGGL(gn_group_kernel<TAG>, dim3(blocks), dim3(512), ldsg, st, (const char*)x0, c0, (const char*)x1, c1, nimg, hw, gpb, nslices, \
+                                       rlanes, gamma, beta, eps, (int)silu, (char*)y, (long)ldy)
+    if (dtype == TT_BF16) TT_GNG(bf16_tag); else if (dtype == TT_F16) TT_GNG(f16_tag); else TT_GNG(f32_tag);
+#undef TT_GNG
+    TT_CHECK_LAUNCH("tt_groupnorm_small");
+    return TT_OK;
+  }
   const int rpb = gn_small_rpb(C, hw);
   const size_t lds = (size_t)2 * rpb * C * sizeof(float);
   // blocks per image: enough to put the apply phase on ~4 x 28..56 CUs without re-reading the image too often
   int parts = 4;
   if (hw < parts * rpb) parts = hw / rpb > 0 ? hw / rpb : 1;
-  hipStream_t st = (hipStream_t)stream;
 #define TT_GNS(TAG, IDX) do { gn_image_opt_in<TAG>(); \
     hipLaunchKernelGGL(gn_stats_image_kernel<TAG>, dim3(nimg, parts), dim3(1024), lds, st, (const char*)x0, c0, (const char*)x1, c1, hw, rpb, \
                        gamma, beta, eps, (float*)nullptr, (float*)nullptr, (char*)y, (long)ldy, (int)silu); } while (0)
