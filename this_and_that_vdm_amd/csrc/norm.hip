@@ -419,18 +419,21 @@ __global__ __launch_bounds__(512) void gn_group_kernel(const char* x0, int c0, c
     }
   }
 }
-// groups per block: the smallest count whose channels fill whole 8-channel vectors, doubled while a row's slice is below 128 bytes
-// and the launch keeps >= 256 blocks.  0: the channel counts do not allow it (a source boundary inside a vector cannot happen:
-// c0 is a multiple of 8)
-static int gn_group_gpb(int nimg, int C, int es) {
+// groups per block: the smallest count whose channels fill whole 8-channel vectors, doubled towards 128-byte row slices while an
+// image keeps at least 8 slices (16 x 28 x 1280: 80-byte slices 47 us, 160-byte slices 26 us).  0: the channel counts do not allow it (a source boundary inside a vector cannot happen: c0 is a multiple of 8).
+// Independent of the image count, so tt_groupnorm_small_supported can answer for the launch.
+static int gn_group_gpb(int C, int es) {
   const int cpg = C / GN_GROUPS;
   int gpb = 1;
   while ((gpb * cpg) & 7) gpb *= 2;                          // <= 8
-  if (gpb > GN_GROUPS) return 0;
-  while (gpb * 2 <= 16 && gpb * cpg * es < 128 && (long)(GN_GROUPS / (gpb * 2)) * nimg >= 256) gpb *= 2;
-  if ((gpb * cpg) >> 3 > 512) return 0;                      // one thread per vector at least
+  while (gpb * 2 <= 4 && gpb * cpg * es < 128) gpb *= 2;
+  if (gpb > 16 || (gpb * cpg) >> 3 > 512) return 0;          // 32 lanes per group in the combination; one thread per vector at least
   return gpb;
 }
+// rows: below, the per-group combination of the row lanes' sums dominates a block that owns three rows per lane (measured: 112 x 2560
+// 41 us against 26 us for the one-block-per-image kernel, 28 x 2560 23 vs 11); above, an image's 32 / gpb blocks walk too many rows
+// each (the temporal VAE decoder's 8 images of 28672+ rows) and the multi-launch route with its thousands of blocks streams better
+constexpr int GN_GROUPED_MIN_ROWS = 256, GN_GROUPED_MAX_ROWS = 16384;
 
 // the per-image kernel keeps [rpb][C] x 2 fp32 partials in dynamic LDS (at most 96 KiB): ONE opt-in (per device) with that maximum
 constexpr int GN_IMAGE_LDS_MAX = 96 * 1024;
@@ -499,9 +502,6 @@ static int gn_small_rpb(int C, int hw) {
   if (rpb > hw) rpb = hw;
   return rpb;
 }
-// images of fewer rows keep the one-block-per-image kernel (measured: 112 x 2560 41 us grouped vs 26 us, 28 x 2560 23 vs 11 -- the
-// per-group combination of the row lanes' sums dominates a block that owns three rows per lane)
-constexpr int GN_GROUPED_MIN_ROWS = 256;
 static int g_gn_grouped = -1;          // TT_GN_GROUPED=0: the round-2 routes (A/B)
 static bool gn_grouped_on() {
   if (g_gn_grouped < 0) { const char* e = getenv("TT_GN_GROUPED"); g_gn_grouped = e ? atoi(e) : 1; }
@@ -510,7 +510,7 @@ static bool gn_grouped_on() {
 extern "C" int tt_groupnorm_small_supported(int32_t hw, int32_t c, int32_t dtype) {
   const int es = dtype == TT_F32 ? 4 : 2;
   if (hw <= 0 || c <= 0 || (c % GN_GROUPS) || (c & 7)) return 0;
-  if (gn_grouped_on() && hw >= GN_GROUPED_MIN_ROWS && gn_group_gpb(1, c, es) > 0) return 1;     // one block per (image, group slice)
+  if (gn_grouped_on() && hw >= GN_GROUPED_MIN_ROWS && hw <= GN_GROUPED_MAX_ROWS && gn_group_gpb(c, es) > 0) return 1;   // one block per (image, group slice)
   return (c >> 3) <= 1024 && (long)hw * c * es <= GN_ONE_BYTES;
 }
 extern "C" int tt_groupnorm_small(const void* x0, int32_t c0, const void* x1, int32_t c1, int32_t nimg, int32_t hw,
@@ -525,7 +525,7 @@ extern "C" int tt_groupnorm_small(const void* x0, int32_t c0, const void* x1, in
     TT_FAIL(TT_EUNSUPPORTED, "tt_groupnorm_small: %d x %d per image is served by tt_groupnorm_stats + tt_groupnorm_apply", hw, C);
   hipStream_t st = (hipStream_t)stream;
   const int es = dtype == TT_F32 ? 4 : 2;
-  if (const int gpb = gn_grouped_on() && hw >= GN_GROUPED_MIN_ROWS ? gn_group_gpb(nimg, C, es) : 0) {
+  if (const int gpb = gn_grouped_on() && hw >= GN_GROUPED_MIN_ROWS && hw <= GN_GROUPED_MAX_ROWS ? gn_group_gpb(C, es) : 0) {
     const int nslices = GN_GROUPS / gpb, nv = (gpb * (C / GN_GROUPS)) >> 3;
     int rlanes = 512 / nv;
     if (rlanes > hw) rlanes = hw;
