@@ -318,11 +318,14 @@ __global__ __launch_bounds__(256, (D == 64 && Elem<Tag>::ES == 2) ? 2 : 1) void 
 
 // ---------------------------------------------------------------------------------------------
 // fp8 spatial self-attention (BASELINE config 5): Q, K, V^T arrive as OCP e4m3 bytes (tt_gemm out_fp8), both products run
-// on v_mfma_f32_32x32x16_fp8_fp8.  Same structure as attn_kernel (S^T = K Q^T, lane = one query, P already the "B" operand
-// of O^T += V^T P^T) with half the operand bytes: a 64-key tile is 4 KiB of K + 4 KiB of V^T (D = 64), a lane reads ONE
-// 16-byte chunk per two MFMAs (8 e4m3 each).  k-slot maps (any map works as long as both operands use it):
-//   QK^T   MFMA 2jj + h of a key block: lane half hi supplies d = 16 (2jj + hi) + 8h .. + 8   (chunk 2jj + hi of the row)
-//   PV     MFMA (kb, h): lane half hi supplies keys kb*32 + 16 hi + 8h .. + 8                 (chunk 2kb + hi of the V^T row)
+// on v_mfma_scale_f32_32x32x64_f8f6f4 with unit block scales (E8M0 0x7f) -- the K = 64 form issues at twice the bf16 rate
+// (tools/mfma_f8f6f4_probe.hip: 4 515 TFLOP/s against 1 745 for v_mfma_f32_32x32x16_fp8_fp8, which runs at the bf16 rate; layout
+// checked there against a CPU product: lane l supplies row l & 31, k slots 32 (l >> 5) .. + 32 as 32 consecutive bytes).
+// Same structure as attn_kernel (S^T = K Q^T, lane = one query, P already the "B" operand of O^T += V^T P^T) with half the
+// operand bytes: a 64-key tile is 4 KiB of K + 4 KiB of V^T (D = 64), a lane reads TWO 16-byte chunks per MFMA (32 e4m3).
+// k-slot maps (any map works as long as both operands use it):
+//   QK^T   MFMA m of a key block: lane half hi supplies d = 16 (4m + hi) .. + 16 and 16 (4m + 2 + hi) .. + 16  (chunks 4m + hi, 4m + 2 + hi)
+//   PV     one MFMA per d block: lane half hi supplies keys 16 hi .. + 16 and 32 + 16 hi .. + 16                (chunks hi, 2 + hi of the V^T row)
 // P is exponentiated with +8 in the exponent (x256: e4m3's subnormal floor 2^-9 would flush every probability below
 // 0.002 of the row maximum; x256 moves the floor to 7.6e-6) -- the factor cancels against the row sum, which is taken
 // over the same scaled values.  Softmax statistics and both accumulations are fp32.
@@ -409,9 +412,19 @@ __global__ __launch_bounds__(256, 2) void attn8_kernel(const AttnP p) {
   for (int db = 0; db < DB; ++db)
 #pragma unroll
     for (int kb = 0; kb < 2; ++kb) vaddr[db][kb] = lds_base + tile_off<VCPR>(db * 32 + l31, 2 * kb + hi);
-  auto mfma8 = [](unsigned a0, unsigned a1, unsigned b0, unsigned b1, f32x16_t c) {
-    return __builtin_amdgcn_mfma_f32_32x32x16_fp8_fp8((long)(((unsigned long)a1 << 32) | a0), (long)(((unsigned long)b1 << 32) | b0), c, 0, 0, 0);
+  typedef int v8i_t __attribute__((ext_vector_type(8)));
+  auto mfma8 = [](const v8i_t& a, const v8i_t& b, f32x16_t c) {            // 32 x 32 x 64, e4m3 x e4m3, unit scales
+    return __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(a, b, c, 0, 0, 0, 0x7f7f7f7f, 0, 0x7f7f7f7f);
   };
+  auto pack8 = [](const raw_u32x4_t& lo, const raw_u32x4_t& hi_) {
+    return (v8i_t){(int)lo.x, (int)lo.y, (int)lo.z, (int)lo.w, (int)hi_.x, (int)hi_.y, (int)hi_.z, (int)hi_.w};
+  };
+  static_assert(JJ % 2 == 0, "two 16-byte chunks per K = 64 MFMA");
+  v8i_t qv[JJ / 2];
+#pragma unroll
+  for (int m = 0; m < JJ / 2; ++m)
+    qv[m] = (v8i_t){(int)qf[2 * m].x, (int)qf[2 * m].y, (int)qf[2 * m].z, (int)qf[2 * m].w,
+                    (int)qf[2 * m + 1].x, (int)qf[2 * m + 1].y, (int)qf[2 * m + 1].z, (int)qf[2 * m + 1].w};
   auto tile = [&](int t, auto buf_tag, auto mask_tag) {
     constexpr int BUF = decltype(buf_tag)::value;
     constexpr bool MASKED = decltype(mask_tag)::value;
@@ -431,13 +444,10 @@ __global__ __launch_bounds__(256, 2) void attn8_kernel(const AttnP p) {
       for (int r = 0; r < 16; ++r) s[kb][r] = 0.f;
     lds_wait<0>();
 #pragma unroll
-    for (int jj = 0; jj < JJ; ++jj)
+    for (int m = 0; m < JJ / 2; ++m)
 #pragma unroll
-      for (int h = 0; h < 2; ++h)
-#pragma unroll
-        for (int kb = 0; kb < 2; ++kb)           // alternate the two accumulators
-          s[kb] = h == 0 ? mfma8(kf[kb][jj].x, kf[kb][jj].y, qf[jj].x, qf[jj].y, s[kb])
-                         : mfma8(kf[kb][jj].z, kf[kb][jj].w, qf[jj].z, qf[jj].w, s[kb]);
+      for (int kb = 0; kb < 2; ++kb)             // alternate the two accumulators
+        s[kb] = mfma8(pack8(kf[kb][2 * m], kf[kb][2 * m + 1]), qv[m], s[kb]);
     __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
     for (int kb = 0; kb < 2; ++kb)
@@ -487,14 +497,10 @@ __global__ __launch_bounds__(256, 2) void attn8_kernel(const AttnP p) {
         for (int r = 0; r < 16; ++r) o[i][r] *= alpha;
     }
     lds_wait<0>();
+    const v8i_t pv = {(int)pf[0][0][0], (int)pf[0][0][1], (int)pf[0][1][0], (int)pf[0][1][1],
+                      (int)pf[1][0][0], (int)pf[1][0][1], (int)pf[1][1][0], (int)pf[1][1][1]};
 #pragma unroll
-    for (int kb = 0; kb < 2; ++kb)
-#pragma unroll
-      for (int h = 0; h < 2; ++h)
-#pragma unroll
-        for (int db = 0; db < DB; ++db)          // alternate the output accumulators
-          o[db] = h == 0 ? mfma8(vf[db][kb].x, vf[db][kb].y, pf[kb][0][0], pf[kb][0][1], o[db])
-                         : mfma8(vf[db][kb].z, vf[db][kb].w, pf[kb][1][0], pf[kb][1][1], o[db]);
+    for (int db = 0; db < DB; ++db) o[db] = mfma8(pack8(vf[db][0], vf[db][1]), pv, o[db]);
     __builtin_amdgcn_sched_barrier(0);
   };
   stage(0, 0);
