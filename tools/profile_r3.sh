@@ -20,8 +20,10 @@ python tools/decode_bench.py --dtype fp16 2>/dev/null | tail -1 >> $P/r3_decode_
 for f in $P/r3_bench_*.json $P/r3_block_*.json; do echo "$f: $(cut -c1-230 $f)"; done
 cat $P/r3_decode_bench.txt
 if [ "${1:-}" != "quick" ]; then
+  # (the probes are built in the build container: hipcc --offload-arch=gfx950 -O3 tools/<name>.hip -o tools/<name>.bin; *.bin is git-ignored and travels with gpurun)
   tools/gemm_pp_probe.bin > $P/r3_gemm_pp_probe.txt 2>&1
   tools/dma_shape_test.bin > $P/r3_dma_shape_test.txt 2>&1
+  tools/mfma_f8f6f4_probe.bin > $P/r3_mfma_f8f6f4_probe.txt 2>&1
   python tools/gemm_bench.py -1 9 --lib 2>/dev/null > $P/r3_gemm_vs_lib.txt
   python -m pytest tests/test_model_gpu.py tests/test_full_size_gpu.py tests/test_vae_decoder_gpu.py -q -s -k "16bit or two_steps or config5 or f32_mode or decoder_matches or zero_context" 2>&1 | grep -v "^$" | grep -v amdgpu.ids | cut -c1-400 > $P/r3_gpu_parity_log.txt
   tail -3 $P/r3_gpu_parity_log.txt
