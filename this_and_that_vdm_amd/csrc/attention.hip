@@ -238,9 +238,14 @@ __global__ __launch_bounds__(256, (D == 64 && Elem<Tag>::ES == 2) ? 2 : 1) void 
 #pragma unroll
       for (int r = 0; r < 16; ++r) mx = fmaxf(mx, s[kb][r]);
     mx = fmaxf(mx, __shfl_xor(mx, 32));
-    const float m_new = fmaxf(m_run, mx * p.scale_log2e);       // running max of the SCALED scores (finite: starts at -1e30)
-    const float alpha = fast_exp2(m_run - m_new);
-    m_run = m_new;
+    // LAZY reference point: softmax is invariant to the subtracted constant, so the running "max" only moves when the true
+    // maximum of the SCALED scores has outgrown it by more than 2^LAZY_LOG2 (P then stays below 256: fine for fp32 sums and
+    // 16-bit P).  After the first tiles almost no tile moves it, and a wave in which no query moved skips the rescale of its
+    // 32 output registers -- a sixth of the tile's VALU issue slots, which (not the MFMAs) bound this kernel at d = 64.
+    constexpr float LAZY_LOG2 = 8.0f;
+    const float mxs = mx * p.scale_log2e;
+    const bool grow = mxs > m_run + LAZY_LOG2;                  // first tile: m_run = -1e30
+    const float m_new = grow ? mxs : m_run;
     float psum = 0.f;
     uint4 pf[2][PH];
 #pragma unroll
@@ -252,13 +257,16 @@ __global__ __launch_bounds__(256, (D == 64 && Elem<Tag>::ES == 2) ? 2 : 1) void 
         for (int r = 0; r < EPC; ++r) { e[r] = fast_exp2(fmaf(s[kb][h * EPC + r], p.scale_log2e, -m_new)); psum += e[r]; }
         pf[kb][h] = pack_chunk<Tag>(e);
       }
-    l_run = l_run * alpha + psum;
-    if (__any(alpha != 1.0f)) {                                 // the running max moved for some query of this wave
+    if (__any(grow)) {                                          // the reference point moved for some query of this wave
+      const float alpha = fast_exp2(m_run - m_new);             // 1 for the queries that kept theirs
+      l_run *= alpha;
 #pragma unroll
       for (int i = 0; i < DB; ++i)
 #pragma unroll
         for (int r = 0; r < 16; ++r) o[i][r] *= alpha;
     }
+    m_run = m_new;
+    l_run += psum;
     // ---- O^T += Vt_tile * P^T : k-slot (hi, e) of read k = kb*PH + h is key kb*32 + 16*hi + EPC*h + e
 #pragma unroll
     for (int i = 0; i < NBV; ++i) {
@@ -326,9 +334,9 @@ __global__ __launch_bounds__(256, (D == 64 && Elem<Tag>::ES == 2) ? 2 : 1) void 
 // k-slot maps (any map works as long as both operands use it):
 //   QK^T   MFMA m of a key block: lane half hi supplies d = 16 (4m + hi) .. + 16 and 16 (4m + 2 + hi) .. + 16  (chunks 4m + hi, 4m + 2 + hi)
 //   PV     one MFMA per d block: lane half hi supplies keys 16 hi .. + 16 and 32 + 16 hi .. + 16                (chunks hi, 2 + hi of the V^T row)
-// P is exponentiated with +8 in the exponent (x256: e4m3's subnormal floor 2^-9 would flush every probability below
-// 0.002 of the row maximum; x256 moves the floor to 7.6e-6) -- the factor cancels against the row sum, which is taken
-// over the same scaled values.  Softmax statistics and both accumulations are fp32.
+// P is exponentiated with a positive offset in the exponent (e4m3's subnormal floor 2^-9 would flush every probability below
+// 0.002 of the row maximum; the offset moves the floor to 1.2e-4 .. 7.6e-6 of it, see the lazy reference point below) -- the
+// factor cancels against the row sum, which is taken over the same scaled values.  Softmax statistics and both accumulations are fp32.
 typedef long fp8x8_t;
 template <typename Tag, int D>
 __global__ __launch_bounds__(256, 2) void attn8_kernel(const AttnP p) {
@@ -469,10 +477,14 @@ __global__ __launch_bounds__(256, 2) void attn8_kernel(const AttnP p) {
 #pragma unroll
       for (int r = 0; r < 16; ++r) mx = fmaxf(mx, s[kb][r]);
     mx = fmaxf(mx, __shfl_xor(mx, 32));
-    const float m_new = fmaxf(m_run, mx * p.scale_log2e);
-    const float alpha = fast_exp2(m_run - m_new);
-    m_run = m_new;
-    const float shift = 8.0f - m_new;                                      // P' = 256 * exp2(s c - m)
+    // lazy reference point as in attn_kernel, with the head room split: the reference moves when the true maximum has outgrown it
+    // by more than 2^4, and P' = 16 * exp2(s c - m) -- so P' stays below 256 (e4m3 tops out at 448) and the row maximum is
+    // stored as 16 .. 256, i.e. e4m3's subnormal floor 2^-9 sits 2^-13 .. 2^-17 below it (eager reference + x256: always 2^-17)
+    constexpr float LAZY_LOG2 = 4.0f;
+    const float mxs = mx * p.scale_log2e;
+    const bool grow = mxs > m_run + LAZY_LOG2;
+    const float m_new = grow ? mxs : m_run;
+    const float shift = 4.0f - m_new;
     float psum = 0.f;
     unsigned pf[2][2][2];                                                  // [kb][h][dword]: 8 e4m3 of keys kb*32 + 16 hi + 8h ..
 #pragma unroll
@@ -489,13 +501,16 @@ __global__ __launch_bounds__(256, 2) void attn8_kernel(const AttnP p) {
         w1 = __builtin_amdgcn_cvt_pk_fp8_f32(e[6], e[7], w1, true);
         pf[kb][h][0] = (unsigned)w0; pf[kb][h][1] = (unsigned)w1;
       }
-    l_run = l_run * alpha + psum;
-    if (__any(alpha != 1.0f)) {
+    if (__any(grow)) {
+      const float alpha = fast_exp2(m_run - m_new);
+      l_run *= alpha;
 #pragma unroll
       for (int i = 0; i < DB; ++i)
 #pragma unroll
         for (int r = 0; r < 16; ++r) o[i][r] *= alpha;
     }
+    m_run = m_new;
+    l_run += psum;
     lds_wait<0>();
     const v8i_t pv = {(int)pf[0][0][0], (int)pf[0][0][1], (int)pf[0][1][0], (int)pf[0][1][1],
                       (int)pf[1][0][0], (int)pf[1][0][1], (int)pf[1][1][0], (int)pf[1][1][1]};
