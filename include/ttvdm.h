@@ -196,7 +196,7 @@ int tt_groupnorm_apply(const void* x0, int32_t c0, const void* x1, int32_t c1, i
                        int32_t dtype, tt_stream_t stream);
 
 /* Statistics + apply in ONE launch for per-image GroupNorm (frames_per_group = 1): y = act(group_norm(x0 | x1)), no workspace, no
- * scale/shift arrays.  Images of >= 256 rows: one block per (image, slice of consecutive groups) -- a group's statistics need only
+ * scale/shift arrays.  Images of 256 to 4096 rows: one block per (image, slice of consecutive groups) -- a group's statistics need only
  * its own channels, so blocks never exchange anything and x is read from HBM once (the apply pass re-reads the slice from L2).
  * Smaller images (at most 640 KiB per image: the 8x14 / 4x7 levels at 256x448): one block per image and row part, each recomputing
  * the image's statistics.  Same result as tt_groupnorm_stats + tt_groupnorm_apply up to fp32 summation order; bit-reproducible.

@@ -367,7 +367,7 @@ def test_groupnorm_one_launch(ops, dtype, c0, c1, h, w, silu):
     close(y, y2.float().cpu(), dtype, scale=2.0)
     small = bool(ops._lib.load().tt_groupnorm_small_supported(h * w, c, ops._code(dtype)))
     # >= 256 rows: one block per (image, group slice), any size; fewer: one block per image up to 640 KiB
-    assert small == (256 <= h * w <= 16384 or h * w * c * (4 if dtype == torch.float32 else 2) <= 640 * 1024)
+    assert small == (256 <= h * w <= 4096 or h * w * c * (4 if dtype == torch.float32 else 2) <= 640 * 1024)
 
 
 @pytest.mark.parametrize("dtype", DTYPES)

@@ -432,8 +432,9 @@ static int gn_group_gpb(int C, int es) {
 }
 // rows: below, the per-group combination of the row lanes' sums dominates a block that owns three rows per lane (measured: 112 x 2560
 // 41 us against 26 us for the one-block-per-image kernel, 28 x 2560 23 vs 11); above, an image's 32 / gpb blocks walk too many rows
-// each (the temporal VAE decoder's 8 images of 28672+ rows) and the multi-launch route with its thousands of blocks streams better
-constexpr int GN_GROUPED_MIN_ROWS = 256, GN_GROUPED_MAX_ROWS = 16384;
+// each and the multi-launch route with its thousands of blocks streams better (64 x 112 x 320: 112 us against 84 us; 32 x 56 x 320:
+// 26 against 29 -- the slices' 80..240-byte row segments reach ~2.5 TB/s, full rows 3 to 4.5)
+constexpr int GN_GROUPED_MIN_ROWS = 256, GN_GROUPED_MAX_ROWS = 4096;
 
 // the per-image kernel keeps [rpb][C] x 2 fp32 partials in dynamic LDS (at most 96 KiB): ONE opt-in (per device) with that maximum
 constexpr int GN_IMAGE_LDS_MAX = 96 * 1024;

@@ -24,7 +24,7 @@ def graph_time(fn, n=20, reps=5):
 def main():
     dt, nimg = torch.bfloat16, 28
     print("TT_GN_GROUPED =", os.environ.get("TT_GN_GROUPED", "1"))
-    for hw, c0, c1 in ((1792, 320, 0), (1792, 320, 320), (1792, 640, 320), (448, 640, 0), (448, 640, 640), (448, 1280, 640), (448, 320, 0),
+    for hw, c0, c1 in ((7168, 320, 0), (7168, 320, 320), (1792, 320, 0), (1792, 320, 320), (1792, 640, 320), (448, 640, 0), (448, 640, 640), (448, 1280, 640), (448, 320, 0),
                        (112, 1280, 0), (112, 1280, 1280), (112, 640, 0), (28, 1280, 0), (28, 1280, 1280)):
         x0 = torch.randn(nimg * hw, c0, device="cuda").to(dt)
         x1 = torch.randn(nimg * hw, c1, device="cuda").to(dt) if c1 else None
