@@ -521,6 +521,7 @@ class TemporalBasicTransformerBlock(_Packable):
         wq2, self.bq2 = fold_layernorm(self.attn2.to_q.weight, None, n2.weight, n2.bias)
         self.wq2 = zr(wq2)
         self.wo2, self.bo2 = cv(self.attn2.to_out[0].weight), _f32(self.attn2.to_out[0].bias)
+        self.bo12 = (self.bo1 + self.bo2).contiguous()      # rows whose cross-attention context is all zeros (forward)
         self.kv = reg.add_kv(self.attn2.to_k, self.attn2.to_v)
         self.ff_in.pack(reg, dtype, norm=self.norm_in)
         self.ff.pack(reg, dtype, norm=self.norm3)
@@ -534,17 +535,22 @@ class TemporalBasicTransformerBlock(_Packable):
         a = torch.empty((g.m, c), dtype=t.dtype, device=t.device)
         ops.temporal_attention(qkv, a, batch=g.batch, frames=g.frames, hw=g.hw, heads=self.attn1.heads,
                                head_dim=self.attn1.dim_head)
-        t = ops.gemm(a, self.wo1, bias=self.bo1, residual=t)
         live = ctx.live_classes(g)
         if live is None:
+            t = ops.gemm(a, self.wo1, bias=self.bo1, residual=t)
             a = _cross_attention(t, self.attn2, self.wq2, self.bq2, self.norm2.eps, self.kv, g, ctx, temporal=True)
             t = ops.gemm(a, self.wo2, bias=self.bo2, residual=t)
         else:
             # Rows of a residue class whose context is all zeros (the CFG uncond context: every other pixel, quirk Q3) get
             # exactly 0 from the cross-attention, i.e. only to_out's bias.  Query projection, attention and output projection
             # run on the live classes alone, as strided row views t[c::CB] (row stride CB*C; the GEMM and the attention take
-            # row strides, the output projection writes in place over its residual).  Exact.
+            # row strides, the output projection writes in place over its residual).  Exact.  The dead classes' "+ bias" rides
+            # on the self-attention output projection, which therefore runs per class too (bias bo1 + bo2 for the dead ones):
+            # no separate pass over half of the rows.
             cb, off, cc = g.ctx_batches, self.kv[0], self.kv[1]
+            for cls in range(cb):
+                tv = t[cls::cb]
+                ops.gemm(a[cls::cb], self.wo1, bias=self.bo1 if cls in live else self.bo12, residual=tv, out=tv)
             for cls in range(cb):
                 tv = t[cls::cb]
                 if cls in live:
@@ -555,6 +561,4 @@ class TemporalBasicTransformerBlock(_Packable):
                                   heads=self.attn2.heads, head_dim=self.attn2.dim_head, mask=1, lk=ctx.s_ctx, k_seq_stride=ctx.s_pad,
                                   v_seq_stride=ctx.s_pad, frames=g.n, ctx_batches=cb, batch0=cls)
                     ops.gemm(a, self.wo2, bias=self.bo2, residual=tv, out=tv)
-                else:
-                    ops.add_rowvec(tv, self.bo2[None, :], rows_per_vec=tv.shape[0], nvec=1, out=tv)
         return self.ff(t, residual=t, blend=x_spatial, alpha=alpha)
