@@ -86,9 +86,19 @@ __global__ __launch_bounds__(1024) void gn_finalize_kernel(const double* ws, int
     double a = 0.0, b = 0.0;
     const int total = fpg * chunks;
     const double* base = ws + ((long)ig * fpg * chunks) * GN_GROUPS * 2;
-    for (int i = slice; i < total; i += GN_SLICES) {
-      const double* o = base + ((long)i * GN_GROUPS + g) * 2;
-      a += o[0]; b += o[1];
+    // this kernel is two blocks of pure latency in front of every temporal GroupNorm's apply pass: keep 8 partials (16-byte loads)
+    // in flight per thread instead of one dependent round trip per partial; the summation order is unchanged
+    int i = slice;
+    for (; i + 7 * GN_SLICES < total; i += 8 * GN_SLICES) {
+      double2 v[8];
+#pragma unroll
+      for (int k = 0; k < 8; ++k) v[k] = *(const double2*)(base + ((long)(i + k * GN_SLICES) * GN_GROUPS + g) * 2);
+#pragma unroll
+      for (int k = 0; k < 8; ++k) { a += v[k].x; b += v[k].y; }
+    }
+    for (; i < total; i += GN_SLICES) {
+      const double2 v = *(const double2*)(base + ((long)i * GN_GROUPS + g) * 2);
+      a += v.x; b += v.y;
     }
     s_a[slice][g] = a; s_b[slice][g] = b;
   }
