@@ -10,6 +10,7 @@ Differences from the reference's execution (results identical up to storage roun
 """
 from __future__ import annotations
 
+import os
 from dataclasses import dataclass
 from typing import Dict, Optional
 
@@ -20,6 +21,8 @@ from ... import ops
 from ..layers import (AlphaBlender, BasicTransformerBlock, Geom, StepContext, TemporalBasicTransformerBlock,
                       TimestepEmbedding, Timesteps, _f32, _gn, _Packable)
 from ..modeling_utils import BaseOutput
+
+FUSE_POS_EMB = os.environ.get("TT_FUSE_POS", "1") != "0"      # A/B switch: frame-position embedding added in the GEMM epilogues
 
 
 @dataclass
@@ -60,6 +63,7 @@ class TransformerSpatioTemporalModel(_Packable):
         self.time_pos_embed.pack(reg, dtype)
         self.alpha = self.time_mixer.alpha_value()
         self._pos_cache = {}
+        self._pos_rows = {}
 
     def _pos_emb(self, frames: int, device) -> torch.Tensor:
         if frames not in self._pos_cache:
@@ -71,7 +75,21 @@ class TransformerSpatioTemporalModel(_Packable):
         xn = _gn(x, None, g, 1, self.gn[0], self.gn[1], 1e-6, False)
         hs = ops.gemm(xn, self.w_in, bias=self.b_in)
         pos = self._pos_emb(g.frames, x.device)
+        # The frame-position embedding (reference :358-359, hidden_states_mix = hidden_states + emb) rides on the last epilogue of
+        # the spatial block, and the time mixer (:371-375) takes its x_spatial back out of that sum inside the temporal block's
+        # last epilogue (TemporalBasicTransformerBlock.forward, blend_fix).  alpha = 1 (no temporal share) keeps the plain order.
+        fuse = FUSE_POS_EMB and self.alpha < 1.0 - 1e-6
+        if fuse:
+            key = (g.frames, g.batch)
+            if key not in self._pos_rows:
+                rows = pos.repeat(g.batch, 1).contiguous()                                  # fp32 [B*F, C]
+                self._pos_rows[key] = (rows, (rows * (-self.alpha / (1.0 - self.alpha))).contiguous())
+            rows, fix = self._pos_rows[key]
         for blk, tblk in zip(self.transformer_blocks, self.temporal_transformer_blocks):
-            hs = blk(hs, g, ctx)
-            hs = tblk(hs, pos, g, ctx, self.alpha)
+            if fuse:
+                hs = blk(hs, g, ctx, out_rowvec=rows)
+                hs = tblk(hs, pos, g, ctx, self.alpha, blend_fix=fix)
+            else:
+                hs = blk(hs, g, ctx)
+                hs = tblk(hs, pos, g, ctx, self.alpha)
         return ops.gemm(hs, self.w_out, bias=self.b_out, residual=x)

@@ -387,10 +387,11 @@ class FeedForward(_Packable):
         self.wg, self.bg = pack_geglu(w.to(dtype), _f32(b))
         self.w2, self.b2 = self.net[2].weight.detach().to(dtype).contiguous(), _f32(self.net[2].bias)
 
-    def forward(self, x, residual, blend=None, alpha=0.0):
-        """x: the UN-normalised hidden states when a LayerNorm was folded in at pack()."""
+    def forward(self, x, residual, blend=None, alpha=0.0, rowvec=None, rowvec_rows: int = 0):
+        """x: the UN-normalised hidden states when a LayerNorm was folded in at pack().
+        rowvec fp32 [groups, C]: row vector added to rows [i * rowvec_rows, (i+1) * rowvec_rows) before residual and blend."""
         hid = ops.gemm(x, self.wg, bias=self.bg, geglu=True, ln_fold=self.ln_fold, ln_eps=self.ln_eps)   # the 8C tensor never exists
-        return ops.gemm(hid, self.w2, bias=self.b2, residual=residual, blend=blend, alpha=alpha)
+        return ops.gemm(hid, self.w2, bias=self.b2, residual=residual, blend=blend, alpha=alpha, rowvec=rowvec, rowvec_rows=rowvec_rows)
 
 
 def _self_attention(x, attn: Attention, wqk, bqk, wv, eps, g: Geom, ctx: StepContext):
@@ -467,14 +468,17 @@ class BasicTransformerBlock(_Packable):
             rows = cache[key] = (torch.tensor(flags, dtype=torch.float32, device=self.bo2.device)[:, None] * self.bo2[None, :]).contiguous()
         return rows
 
-    def forward(self, x, g: Geom, ctx: StepContext):
+    def forward(self, x, g: Geom, ctx: StepContext, out_rowvec=None):
+        """out_rowvec fp32 [N, C] (one row per frame of the batch): added to the block's output -- the frame-position embedding the
+        temporal block that follows would otherwise add in a pass of its own (TransformerSpatioTemporalModel.forward)."""
+        ff_rv = dict(rowvec=out_rowvec, rowvec_rows=g.hw) if out_rowvec is not None else {}
         a = _self_attention(x, self.attn1, self.wqk, self.bqk, self.wv, self.norm1.eps, g, ctx)
         live = ctx.live_batches(g)
         if live is None:
             x = ops.gemm(a, self.wo1, bias=self.bo1, residual=x)
             a = _cross_attention(x, self.attn2, self.wq2, self.bq2, self.norm2.eps, self.kv, g, ctx, temporal=False)
             x = ops.gemm(a, self.wo2, bias=self.bo2, residual=x)
-            return self.ff(x, residual=x)
+            return self.ff(x, residual=x, **ff_rv)
         # Batch elements with an all-zero context (the CFG uncond half): K = V = 0, so their cross-attention output is exactly 0
         # and the layer adds to_out's bias only -- that bias rides on the self-attention output projection as a per-batch row
         # vector, and query projection / attention / output projection run on the rows of the live elements alone (in place:
@@ -487,7 +491,7 @@ class BasicTransformerBlock(_Packable):
             gl = Geom(count, g.frames, g.h, g.w, g.batch0 + first, g.ctx_batches)
             a = _cross_attention(xs, self.attn2, self.wq2, self.bq2, self.norm2.eps, self.kv, gl, ctx, temporal=False)
             ops.gemm(a, self.wo2, bias=self.bo2, residual=xs, out=xs)
-        return self.ff(x, residual=x)
+        return self.ff(x, residual=x, **ff_rv)
 
 
 class TemporalBasicTransformerBlock(_Packable):
@@ -526,10 +530,16 @@ class TemporalBasicTransformerBlock(_Packable):
         self.ff_in.pack(reg, dtype, norm=self.norm_in)
         self.ff.pack(reg, dtype, norm=self.norm3)
 
-    def forward(self, x_spatial, pos_emb, g: Geom, ctx: StepContext, alpha: float):
-        """x_spatial [M,C]; pos_emb fp32 [F,C].  Returns alpha*x_spatial + (1-alpha)*temporal(x_spatial + pos_emb)."""
+    def forward(self, x_spatial, pos_emb, g: Geom, ctx: StepContext, alpha: float, blend_fix=None):
+        """x_spatial [M,C]; pos_emb fp32 [F,C].  Returns alpha*x_spatial + (1-alpha)*temporal(x_spatial + pos_emb).
+        blend_fix fp32 [N, C]: x_spatial ALREADY carries the frame-position embedding e (the spatial block added it in its last
+        epilogue), and blend_fix = -alpha / (1 - alpha) * e per frame row: the final blend alpha * (x + e) + (1 - alpha) * (v +
+        blend_fix) equals alpha * x + (1 - alpha) * v -- no pass that materialises x + e, no second copy of x."""
         c = x_spatial.shape[1]
-        xs = ops.add_rowvec(x_spatial, pos_emb, rows_per_vec=g.hw, nvec=g.frames)        # + frame-position embedding
+        if blend_fix is None:
+            xs = ops.add_rowvec(x_spatial, pos_emb, rows_per_vec=g.hw, nvec=g.frames)        # + frame-position embedding
+        else:
+            xs = x_spatial
         t = self.ff_in(xs, residual=xs)
         qkv = ops.gemm(t, self.wqkv, bias=self.bqkv, ln_fold=1, ln_eps=self.norm1.eps)
         a = torch.empty((g.m, c), dtype=t.dtype, device=t.device)
@@ -561,4 +571,6 @@ class TemporalBasicTransformerBlock(_Packable):
                                   heads=self.attn2.heads, head_dim=self.attn2.dim_head, mask=1, lk=ctx.s_ctx, k_seq_stride=ctx.s_pad,
                                   v_seq_stride=ctx.s_pad, frames=g.n, ctx_batches=cb, batch0=cls)
                     ops.gemm(a, self.wo2, bias=self.bo2, residual=tv, out=tv)
+        if blend_fix is not None:
+            return self.ff(t, residual=t, blend=xs, alpha=alpha, rowvec=blend_fix, rowvec_rows=g.hw)
         return self.ff(t, residual=t, blend=x_spatial, alpha=alpha)
