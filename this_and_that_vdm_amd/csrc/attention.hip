@@ -232,40 +232,46 @@ __global__ __launch_bounds__(256, (D == 64 && Elem<Tag>::ES == 2) ? 2 : 1) void 
           if (j >= p.lk) s[kb][r] = -INFINITY;
         }
     }
-    float mx = s[0][0];
-#pragma unroll
-    for (int kb = 0; kb < 2; ++kb)
-#pragma unroll
-      for (int r = 0; r < 16; ++r) mx = fmaxf(mx, s[kb][r]);
-    mx = fmaxf(mx, __shfl_xor(mx, 32));
-    // LAZY reference point: softmax is invariant to the subtracted constant, so the running "max" only moves when the true
-    // maximum of the SCALED scores has outgrown it by more than 2^LAZY_LOG2 (P then stays below 256: fine for fp32 sums and
-    // 16-bit P).  After the first tiles almost no tile moves it, and a wave in which no query moved skips the rescale of its
-    // 32 output registers -- a sixth of the tile's VALU issue slots, which (not the MFMAs) bound this kernel at d = 64.
-    constexpr float LAZY_LOG2 = 8.0f;
-    const float mxs = mx * p.scale_log2e;
-    const bool grow = mxs > m_run + LAZY_LOG2;                  // first tile: m_run = -1e30
-    const float m_new = grow ? mxs : m_run;
+    // LAZY reference point, OPTIMISTIC evaluation.  Softmax is invariant to the subtracted constant, so the running "max" m_run
+    // only has to keep exp2 in range.  Fast path: exponentiate against the m_run we have and look at the row sum -- if every
+    // lane's partial sum of this tile is <= 2^14, no P exceeds 2^14 (fine for fp32 sums and 16-bit P) and the tile is done
+    // WITHOUT computing a maximum: the 22 max instructions, the lane exchange and the rescale of 32 output registers leave the
+    // stream that bounds this kernel at d = 64 (VALU, not MFMA).  Slow path (first tile: m_run = -1e30 gives inf; later only when
+    // the scores outgrow the reference by ~2^8 or more): take the tile's true maximum as the new reference, rescale, redo P.
+    constexpr float PSUM_OK = 16384.0f;
     float psum = 0.f;
     uint4 pf[2][PH];
+    auto exponentiate = [&](float m_ref) {
+      psum = 0.f;
 #pragma unroll
-    for (int kb = 0; kb < 2; ++kb)
+      for (int kb = 0; kb < 2; ++kb)
 #pragma unroll
-      for (int h = 0; h < PH; ++h) {
-        float e[EPC];
+        for (int h = 0; h < PH; ++h) {
+          float e[EPC];
 #pragma unroll
-        for (int r = 0; r < EPC; ++r) { e[r] = fast_exp2(fmaf(s[kb][h * EPC + r], p.scale_log2e, -m_new)); psum += e[r]; }
-        pf[kb][h] = pack_chunk<Tag>(e);
-      }
-    if (__any(grow)) {                                          // the reference point moved for some query of this wave
-      const float alpha = fast_exp2(m_run - m_new);             // 1 for the queries that kept theirs
+          for (int r = 0; r < EPC; ++r) { e[r] = fast_exp2(fmaf(s[kb][h * EPC + r], p.scale_log2e, -m_ref)); psum += e[r]; }
+          pf[kb][h] = pack_chunk<Tag>(e);
+        }
+    };
+    exponentiate(m_run);
+    if (__any(!(psum <= PSUM_OK))) {                            // (also catches inf / NaN)
+      float mx = s[0][0];
+#pragma unroll
+      for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) mx = fmaxf(mx, s[kb][r]);
+      mx = fmaxf(mx, __shfl_xor(mx, 32));
+      const float mxs = mx * p.scale_log2e;
+      const float m_new = fmaxf(m_run, mxs);                    // per query: both lane halves agree
+      const float alpha = fast_exp2(m_run - m_new);             // 1 for the queries whose reference stays
       l_run *= alpha;
 #pragma unroll
       for (int i = 0; i < DB; ++i)
 #pragma unroll
         for (int r = 0; r < 16; ++r) o[i][r] *= alpha;
+      m_run = m_new;
+      exponentiate(m_run);
     }
-    m_run = m_new;
     l_run += psum;
     // ---- O^T += Vt_tile * P^T : k-slot (hi, e) of read k = kb*PH + h is key kb*32 + 16*hi + EPC*h + e
 #pragma unroll
