@@ -277,6 +277,25 @@ def test_attention_softmax_rescale_branch(ops, dtype):
                   k_seq_stride=l, v_seq_stride=l)
     close(out[None], _sdpa(q, k, v, 1), dtype)
 
+@pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("growth", [6.0, 40.0, 400.0])
+def test_attention_scores_growing_along_the_keys(ops, dtype, growth):
+    """The softmax reference point is lazy and evaluated optimistically (a tile is accepted when its row sums stay below 2^14, the
+    maximum is computed only when they do not): keys whose scores keep GROWING along the sequence force the slow path again and
+    again, by a little (stays on the fast path with a stale reference), by a lot, and by enough to overflow exp2 (inf caught by
+    the same check).  Scaled scores span `growth` * log2(e) / sqrt(d) * |q|^2 octaves over the sequence."""
+    l, d = 640, 64
+    q, k, v = (rnd(1, l, d, dtype=torch.float32, seed=s) for s in (1, 2, 3))
+    ramp = torch.linspace(0.0, 1.0, l)[:, None]
+    k = k * 0.3 + ramp * growth * q[0, 5:6] / q[0, 5].norm()          # key j leans towards query 5 by j / l * growth
+    q, k, v = q.to(dtype), k.to(dtype), v.to(dtype)
+    vt = v[0].T.contiguous()
+    out = torch.empty(l, d, dtype=dtype, device="cuda")
+    ops.attention(q[0].cuda(), k[0].cuda(), vt.cuda(), out, nseq=1, lq=l, heads=1, head_dim=d, mask=0, lk=l,
+                  k_seq_stride=l, v_seq_stride=l)
+    assert bool(torch.isfinite(out.float()).all())
+    close(out[None], _sdpa(q, k, v, 1), dtype)
+
 
 @pytest.mark.parametrize("dtype", DTYPES)
 @pytest.mark.parametrize("s", [1, 5, 78])
