@@ -477,45 +477,48 @@ __global__ __launch_bounds__(256, 2) void attn8_kernel(const AttnP p) {
           if (j >= p.lk) s[kb][r] = -INFINITY;
         }
     }
-    float mx = s[0][0];
-#pragma unroll
-    for (int kb = 0; kb < 2; ++kb)
-#pragma unroll
-      for (int r = 0; r < 16; ++r) mx = fmaxf(mx, s[kb][r]);
-    mx = fmaxf(mx, __shfl_xor(mx, 32));
-    // lazy reference point as in attn_kernel, with the head room split: the reference moves when the true maximum has outgrown it
-    // by more than 2^4, and P' = 16 * exp2(s c - m) -- so P' stays below 256 (e4m3 tops out at 448) and the row maximum is
-    // stored as 16 .. 256, i.e. e4m3's subnormal floor 2^-9 sits 2^-13 .. 2^-17 below it (eager reference + x256: always 2^-17)
-    constexpr float LAZY_LOG2 = 4.0f;
-    const float mxs = mx * p.scale_log2e;
-    const bool grow = mxs > m_run + LAZY_LOG2;
-    const float m_new = grow ? mxs : m_run;
-    const float shift = 4.0f - m_new;
+    // lazy reference point, optimistic evaluation as in attn_kernel, with e4m3's range in mind: P' = 8 * exp2(s c - m_run), and
+    // the tile is accepted when every lane's partial row sum is <= 448 -- then no P' exceeds e4m3's largest value.  The slow path
+    // (first tile, or scores that outgrew the reference by ~2^5) makes the tile's true maximum the reference, so a row maximum
+    // is stored as 8 .. 448 and e4m3's subnormal floor 2^-9 sits 2^-12 .. 2^-17.8 below it (eager reference + x256: 2^-17).
+    constexpr float PSUM_OK = 448.0f, P_LOG2 = 3.0f;
     float psum = 0.f;
     unsigned pf[2][2][2];                                                  // [kb][h][dword]: 8 e4m3 of keys kb*32 + 16 hi + 8h ..
+    auto exponentiate = [&](float shift) {
+      psum = 0.f;
 #pragma unroll
-    for (int kb = 0; kb < 2; ++kb)
+      for (int kb = 0; kb < 2; ++kb)
 #pragma unroll
-      for (int h = 0; h < 2; ++h) {
-        float e[8];
+        for (int h = 0; h < 2; ++h) {
+          float e[8];
 #pragma unroll
-        for (int r = 0; r < 8; ++r) { e[r] = fast_exp2(fmaf(s[kb][h * 8 + r], p.scale_log2e, shift)); psum += e[r]; }
-        int w0 = 0, w1 = 0;
-        w0 = __builtin_amdgcn_cvt_pk_fp8_f32(e[0], e[1], w0, false);
-        w0 = __builtin_amdgcn_cvt_pk_fp8_f32(e[2], e[3], w0, true);
-        w1 = __builtin_amdgcn_cvt_pk_fp8_f32(e[4], e[5], w1, false);
-        w1 = __builtin_amdgcn_cvt_pk_fp8_f32(e[6], e[7], w1, true);
-        pf[kb][h][0] = (unsigned)w0; pf[kb][h][1] = (unsigned)w1;
-      }
-    if (__any(grow)) {
+          for (int r = 0; r < 8; ++r) { e[r] = fast_exp2(fmaf(s[kb][h * 8 + r], p.scale_log2e, shift)); psum += e[r]; }
+          int w0 = 0, w1 = 0;
+          w0 = __builtin_amdgcn_cvt_pk_fp8_f32(e[0], e[1], w0, false);
+          w0 = __builtin_amdgcn_cvt_pk_fp8_f32(e[2], e[3], w0, true);
+          w1 = __builtin_amdgcn_cvt_pk_fp8_f32(e[4], e[5], w1, false);
+          w1 = __builtin_amdgcn_cvt_pk_fp8_f32(e[6], e[7], w1, true);
+          pf[kb][h][0] = (unsigned)w0; pf[kb][h][1] = (unsigned)w1;
+        }
+    };
+    exponentiate(P_LOG2 - m_run);
+    if (__any(!(psum <= PSUM_OK))) {                                       // (also catches inf / NaN: first tile, m_run = -1e30)
+      float mx = s[0][0];
+#pragma unroll
+      for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) mx = fmaxf(mx, s[kb][r]);
+      mx = fmaxf(mx, __shfl_xor(mx, 32));
+      const float m_new = fmaxf(m_run, mx * p.scale_log2e);
       const float alpha = fast_exp2(m_run - m_new);
       l_run *= alpha;
 #pragma unroll
       for (int i = 0; i < DB; ++i)
 #pragma unroll
         for (int r = 0; r < 16; ++r) o[i][r] *= alpha;
+      m_run = m_new;
+      exponentiate(P_LOG2 - m_run);
     }
-    m_run = m_new;
     l_run += psum;
     lds_wait<0>();
     const v8i_t pv = {(int)pf[0][0][0], (int)pf[0][0][1], (int)pf[0][1][0], (int)pf[0][1][1],
