@@ -162,8 +162,9 @@ typedef struct TtAttnArgs {
   int32_t dtype;
   int32_t batch0;                      /* masks 1,2: batch index of sequence 0 (a launch may cover a sub-range of the batch) */
   /* fp8 != 0 (mask 0 only): q, k, vt hold OCP e4m3 bytes (strides in bytes = elements; written by tt_gemm out_fp8),
-   * QK^T and PV run on v_mfma_f32_32x32x16_fp8_fp8 with P = 256 * exp2(..) converted to e4m3 (the factor cancels against the
-   * row sum); softmax statistics and the output accumulation stay fp32, `out` is `dtype` (16-bit).  Scales are 1: the
+   * QK^T and PV run on v_mfma_scale_f32_32x32x64_f8f6f4 (unit block scales) with P = 8 * exp2(s c - m) converted to e4m3, m a
+   * lazily updated reference that keeps P inside e4m3's range (the factor cancels against the row sum); softmax statistics
+   * and the output accumulation stay fp32, `out` is `dtype` (16-bit).  Scales are 1: the
    * operands are LayerNorm-ed projections, far inside e4m3's +-448.  Its tolerance is e4m3's (3 mantissa bits), see
    * tests/test_ops_gpu.py::test_attention_fp8. */
   int32_t fp8;

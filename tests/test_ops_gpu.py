@@ -219,7 +219,7 @@ def test_attention_self(ops, dtype, l, heads, d):
 @pytest.mark.parametrize("dtype", DTYPES16)
 @pytest.mark.parametrize("l,heads,d", [(200, 2, 64), (1792, 1, 64), (448, 2, 64), (100, 1, 128)])
 def test_attention_fp8(ops, dtype, l, heads, d):
-    """BASELINE config 5: spatial self-attention on OCP e4m3 operands (v_mfma_f32_32x32x16_fp8_fp8), 16-bit output.
+    """BASELINE config 5: spatial self-attention on OCP e4m3 operands (v_mfma_scale_f32_32x32x64_f8f6f4, unit scales), 16-bit output.
     Checked against fp32 SDPA on the SAME e4m3 values (what the kernel adds on top: P rounded to e4m3, 3 mantissa bits,
     inside fp32 sums) at rtol = atol = 3e-2, and -- printed -- against SDPA on the unquantised 16-bit values."""
     nseq, c = 2, heads * d
