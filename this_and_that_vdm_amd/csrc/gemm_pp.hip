@@ -134,15 +134,32 @@ __global__ __launch_bounds__(512, 2) void gemm_pp_kernel(const GemmP p) {
     for (int ks = 0; ks < 4; ++ks) bf[ks] = lds_read16_raw(sbase + (2 + j) * REG + b_addr[ks]);
   };
   // the 8 MFMAs of quadrant (I2, J)
+  int c_ks = 0, c_it = 0;                                    // consumer cursor: slab inside the tile, tile
+  // GEGLU instances, first slab of a tile: the first MFMA of every fragment takes the constant 0 as its C operand -- the epilogue
+  // does not have to clear 128 accumulator registers per lane and tile (-2..3 % at K = 320 / 640; the plain instances lose 4 %
+  // with it and the LayerNorm + plain one spills, so they keep the clearing loop)
+  constexpr bool ZERO_BY_MFMA = GEGLU != 0;
   auto mma = [&](auto i2_tag, auto j_tag) {
     constexpr int I2 = decltype(i2_tag)::value, J = decltype(j_tag)::value;
     __builtin_amdgcn_s_setprio(1);
+    if (ZERO_BY_MFMA && c_ks == 0) {
+      f32x16_t z;
 #pragma unroll
-    for (int ks = 0; ks < 4; ++ks)
+      for (int r = 0; r < 16; ++r) z[r] = 0.f;
 #pragma unroll
-      for (int i = 0; i < 2; ++i)
-        acc[I2 * 2 + i][J] = Cvt<Tag>::mfma32(make_uint4(bf[ks].x, bf[ks].y, bf[ks].z, bf[ks].w),
-                                              make_uint4(af[i][ks].x, af[i][ks].y, af[i][ks].z, af[i][ks].w), acc[I2 * 2 + i][J]);
+      for (int ks = 0; ks < 4; ++ks)
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+          acc[I2 * 2 + i][J] = Cvt<Tag>::mfma32(make_uint4(bf[ks].x, bf[ks].y, bf[ks].z, bf[ks].w),
+                                                make_uint4(af[i][ks].x, af[i][ks].y, af[i][ks].z, af[i][ks].w), ks == 0 ? z : acc[I2 * 2 + i][J]);
+    } else {
+#pragma unroll
+      for (int ks = 0; ks < 4; ++ks)
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+          acc[I2 * 2 + i][J] = Cvt<Tag>::mfma32(make_uint4(bf[ks].x, bf[ks].y, bf[ks].z, bf[ks].w),
+                                                make_uint4(af[i][ks].x, af[i][ks].y, af[i][ks].z, af[i][ks].w), acc[I2 * 2 + i][J]);
+    }
     __builtin_amdgcn_s_setprio(0);
   };
   // LayerNorm sums of the A half in the fragment registers (each element of A passes through exactly one p0 / p2 per slab).  They
@@ -174,7 +191,6 @@ __global__ __launch_bounds__(512, 2) void gemm_pp_kernel(const GemmP p) {
   bar();
   if (grp == 1) bar();                                       // group 1 runs one barrier behind group 0
 
-  int c_ks = 0, c_it = 0;
   const unsigned strip = lds_base + STRIP_OFF + wid * 4096;
 
   // ---- epilogue of one tile (both groups together; no barrier inside: every wave works on its own strip)
@@ -289,10 +305,12 @@ __global__ __launch_bounds__(512, 2) void gemm_pp_kernel(const GemmP p) {
                                                  (gm < p.m && oc * 2 < p.n) ? (int)(((long)gm * p.ldo + oc) * ES) : kInv, 0, 0);
         }
       }
+      if constexpr (!ZERO_BY_MFMA) {
 #pragma unroll
-      for (int j = 0; j < FN; ++j)
+        for (int j = 0; j < FN; ++j)
 #pragma unroll
-        for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+          for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+      }
     }
   };
 
