@@ -66,10 +66,14 @@ __global__ __launch_bounds__(512, 2) void gemm_pp_kernel(const GemmP p) {
   // region row rr (0..127) -> tile row: A-lo (rr/64)*128 + rr%64, A-hi +64 ; W-lo (rr/32)*64 + rr%32, W-hi +32
   int pv[4][2];
   int p_it = 0, p_ks = 0;
+  // origins of the producer's last two tiles, by tile parity: the consumer (at most one tile behind) takes its tile's origin from
+  // here instead of repeating the integer divisions of tile_of() in its first phase and in its epilogue
+  int q_m0[2] = {0, 0}, q_n0[2] = {0, 0};
   auto producer_tile = [&](int it) {
     int m0 = 0, n0 = 0;
     const bool ok = it < my_tiles;
     if (ok) tile_of(it, m0, n0);
+    if (it & 1) { q_m0[1] = m0; q_n0[1] = n0; } else { q_m0[0] = m0; q_n0[0] = n0; }
 #pragma unroll
     for (int i = 0; i < 2; ++i) {
       const int c = i * 512 + tid, rr = c >> 3, ch = (c & 7) ^ tile_swz<CPR>(rr);
@@ -194,9 +198,9 @@ __global__ __launch_bounds__(512, 2) void gemm_pp_kernel(const GemmP p) {
   const unsigned strip = lds_base + STRIP_OFF + wid * 4096;
 
   // ---- epilogue of one tile (both groups together; no barrier inside: every wave works on its own strip)
+  int c_m0 = 0, c_n0 = 0;                                    // origin of the consumer's tile (set in p0 of its first slab)
   auto epilogue = [&]() {
-    int m0, n0;
-    tile_of(c_it, m0, n0);
+    const int m0 = c_m0, n0 = c_n0;
     ++c_it;
 
     __builtin_amdgcn_sched_barrier(0);
@@ -320,8 +324,8 @@ __global__ __launch_bounds__(512, 2) void gemm_pp_kernel(const GemmP p) {
     // ---- p0 (0,0): A-lo + W-lo ; DMA: [bias of this tile] + W-lo of slab s+1 (the other slot; released in p3 of slab s-1)
     read_a(sb, 0); read_b(sb, 0);
     if (c_ks == 0) {
-      int m0, n0;
-      tile_of(c_it < my_tiles ? c_it : 0, m0, n0);
+      const int m0 = (c_it & 1) ? q_m0[1] : q_m0[0], n0 = (c_it & 1) ? q_n0[1] : q_n0[0];
+      c_m0 = m0; c_n0 = n0;
       const int gn = n0 + wc * 64 + lane;
       __builtin_amdgcn_raw_ptr_buffer_load_lds(rb, (__attribute__((address_space(3))) void*)(smem + STRIP_OFF + wid * 4096), 4,
                                                gn < p.n ? gn * 4 : kInv, 0, 0, 0);
