@@ -252,7 +252,14 @@ __global__ __launch_bounds__(512, 2) void gemm_pp_kernel(const GemmP p) {
         ln_s[i] = ln_q[i] = 0.f;
       }
     }
+    // (acc * rs + b) * scale as ONE fused multiply-add per value: scale folded into rs and into the bias registers
     const float scale = p.acc_scale;
+#pragma unroll
+    for (int i = 0; i < FM; ++i) rs[i] *= scale;
+#pragma unroll
+    for (int j = 0; j < FN; ++j)
+#pragma unroll
+      for (int g = 0; g < 4; ++g) { b4[j][g].x *= scale; b4[j][g].y *= scale; b4[j][g].z *= scale; b4[j][g].w *= scale; }
 #pragma unroll
     for (int i = 0; i < FM; ++i) {
       const int mb = m0 + wr * WTM + i * 32;
@@ -263,8 +270,8 @@ __global__ __launch_bounds__(512, 2) void gemm_pp_kernel(const GemmP p) {
 #pragma unroll
           for (int g = 0; g < 4; ++g) {
             const float4 b = b4[j][g];
-            const float v0 = (acc[i][j][g * 4] * rs[i] + b.x) * scale, v1 = (acc[i][j][g * 4 + 1] * rs[i] + b.y) * scale;
-            const float v2 = (acc[i][j][g * 4 + 2] * rs[i] + b.z) * scale, v3 = (acc[i][j][g * 4 + 3] * rs[i] + b.w) * scale;
+            const float v0 = fmaf(acc[i][j][g * 4], rs[i], b.x), v1 = fmaf(acc[i][j][g * 4 + 1], rs[i], b.y);
+            const float v2 = fmaf(acc[i][j][g * 4 + 2], rs[i], b.z), v3 = fmaf(acc[i][j][g * 4 + 3], rs[i], b.w);
             const int col = j * 32 + 8 * g + 4 * hi;                       // first of 4 columns: byte col*2 inside chunk col/8
             lds_write8_raw(strip + l31 * 128 + (((col >> 3) ^ (l31 & 7)) << 4) + ((col & 7) << 1), pack2<Tag>(v0, v1), pack2<Tag>(v2, v3));
           }
@@ -292,7 +299,7 @@ __global__ __launch_bounds__(512, 2) void gemm_pp_kernel(const GemmP p) {
             float v[4];
 #pragma unroll
             for (int e = 0; e < 4; ++e)
-              v[e] = ((acc[i][j][(2 * tt) * 4 + e] * rs[i] + bvv[e]) * scale) * gelu_erf_f((acc[i][j][(2 * tt + 1) * 4 + e] * rs[i] + bgv[e]) * scale);
+              v[e] = fmaf(acc[i][j][(2 * tt) * 4 + e], rs[i], bvv[e]) * gelu_erf_f(fmaf(acc[i][j][(2 * tt + 1) * 4 + e], rs[i], bgv[e]));
             const int col = j * 16 + tt * 8 + 4 * hi;                      // output column inside the wave's 32
             lds_write8_raw(strip + l31 * 64 + (((col >> 3) ^ ((l31 >> 1) & 3)) << 4) + ((col & 7) << 1), pack2<Tag>(v[0], v[1]), pack2<Tag>(v[2], v[3]));
           }
