@@ -262,10 +262,15 @@ def stub_cpu_main(a, world: int, rank: int) -> int:
     """The rank plumbing of main() (rendezvous, barrier-bracketed timing, max over ranks, rank-0 JSON line) with the GPU
     loop replaced by a sleep, on gloo.  Exists only so the N > 1 launcher path is testable without GPUs."""
     import torch.distributed as dist
-    from this_and_that_vdm_amd.dist import max_over_ranks
+    from this_and_that_vdm_amd.dist import RendezvousError, init_ranks, max_over_ranks
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("gloo")
+        try:                                     # the same fail-loud start-up as the GPU path (gloo instead of RCCL)
+            init_ranks("gloo", rank, world, int(os.environ.get("LOCAL_RANK", "0")),
+                       timeout_s=float(os.environ.get("TT_BENCH_RENDEZVOUS_TIMEOUT_S", "180")))
+        except RendezvousError as e:
+            print(json.dumps({"metric": "stub (launcher self-test, no GPU work)", "value": None, "n_gpus": world, "error": f"rank {rank}: {e}"}), flush=True)
+            raise SystemExit(3)
         dist.barrier()
     t0 = time.perf_counter()
     time.sleep(0.002 * a.steps * (1 + rank))
@@ -319,14 +324,23 @@ def main():
     one_gpu = os.environ.get("TT_BENCH_ONE_GPU") == "1"
     if one_gpu:
         local = 0
-    torch.cuda.set_device(local)
-    device = torch.device("cuda", local)
-    if world > 1:
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        if one_gpu:
-            torch.distributed.init_process_group("gloo")
-        else:
-            torch.distributed.init_process_group("nccl", device_id=device)
+    from this_and_that_vdm_amd.dist import RendezvousError, gather_floats, init_ranks
+    rendezvous_s = 0.0
+    try:
+        # rank / LOCAL_RANK / device-count check, process group with a finite timeout, 1-element broadcast + all-reduce: a wrong
+        # mapping or a dead transport ends the job HERE with its cause in the JSON line, not inside the 3 GB weight broadcast
+        if not one_gpu and not (0 <= local < torch.cuda.device_count()):
+            raise RendezvousError(f"LOCAL_RANK {local} has no GPU: {torch.cuda.device_count()} device(s) visible to rank {rank}")
+        torch.cuda.set_device(local)
+        device = torch.device("cuda", local)
+        if world > 1:
+            os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+            rendezvous_s = init_ranks("gloo" if one_gpu else "nccl", rank, world, local, device=None if one_gpu else device,
+                                      timeout_s=float(os.environ.get("TT_BENCH_RENDEZVOUS_TIMEOUT_S", "180")))
+    except RendezvousError as e:
+        print(json.dumps({"metric": "denoise-steps/sec (14-frame 256x448 VGL, 25 steps)", "value": None, "unit": "denoise-steps/s",
+                          "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "error": f"rank {rank}: {e}"}), flush=True)
+        raise SystemExit(3)
     dtype = {"bf16": torch.bfloat16, "fp16": torch.float16, "f32": torch.float32}[a.dtype]
     peak = PEAK_TFLOPS if a.dtype != "f32" else PEAK_TFLOPS_F32
     if world > 1:                                # N ranks share the host's cores during prepare() / packing
@@ -357,15 +371,11 @@ def main():
     fence()
     dt = time.perf_counter() - t0
     from this_and_that_vdm_amd.dist import max_over_ranks
-    per_rank_ms, checksums = [dt / a.steps * 1e3], [checksum]
-    if world > 1:
-        gdev = "cpu" if one_gpu else device
-        mine = torch.tensor([dt / a.steps * 1e3, float(checksum % (1 << 52))], dtype=torch.float64, device=gdev)
-        allv = [torch.zeros_like(mine) for _ in range(world)]
-        torch.distributed.all_gather(allv, mine)
-        per_rank_ms = [float(v[0]) for v in allv]
-        checksums = [int(v[1]) for v in allv]
-    dt = max_over_ranks(dt, device)
+    gdev = "cpu" if one_gpu else device
+    allv = gather_floats([dt / a.steps * 1e3, float(checksum % (1 << 52)), getattr(build_models, "prepare_s", 0.0), bcast_s or 0.0], gdev)
+    per_rank_ms, checksums = [v[0] for v in allv], [int(v[1]) for v in allv]
+    per_rank_pack_s, per_rank_bcast_s = [v[2] for v in allv], [v[3] for v in allv]
+    dt = max_over_ranks(dt, gdev)
     finite = bool(torch.isfinite(loop.result()).all().item())
 
     roofline, extras = None, {}
@@ -418,7 +428,9 @@ def main():
                        "hipgraph": True, "finite_output": finite, "spatial_self_attention": a.attn,
                        "step_tflop_algorithmic": step_tflop,
                        "step_mfma_frac_of_peak": step_tflop / (ms * 1e-3) / peak,
-                       "weight_broadcast_s": bcast_s, "weight_packing_s_per_rank": getattr(build_models, "prepare_s", None),
+                       "weight_broadcast_s": max(per_rank_bcast_s) if world > 1 else None, "rendezvous_s": rendezvous_s if world > 1 else None,
+                       "weight_packing_s_per_rank": per_rank_pack_s if world > 1 else getattr(build_models, "prepare_s", None),
+                       "multi_gpu_measured_on_hardware": None if world == 1 else (not one_gpu),
                        "ms_per_step_per_rank": per_rank_ms,
                        "weights_identical_on_all_ranks": len(set(checksums)) == 1, "kernel_source_sha16": csrc_hash(), **extras},
             "roofline": roofline, "cpu_baseline": cpu,

@@ -57,3 +57,55 @@ def test_weight_broadcast_sharding_and_max_timing():
 def test_single_process_is_a_no_op():
     m = torch.nn.Linear(4, 4)
     assert broadcast_model_(m) == 0.0 and max_over_ranks(3.0, "cpu") == 3.0
+
+
+def _init_worker(rank, world, port, q):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    from this_and_that_vdm_amd.dist import gather_floats, init_ranks
+    secs = init_ranks("gloo", rank, world, rank, timeout_s=60)
+    got = gather_floats([float(rank), 10.0 + rank], "cpu")
+    q.put((rank, secs > 0.0, got))
+    dist.destroy_process_group()
+
+
+def test_fail_loud_rendezvous_probe_and_gather():
+    """init_ranks: process group with a finite timeout + 1-element broadcast / all-reduce probe; gather_floats: per-rank values."""
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_init_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = sorted(q.get(timeout=120) for _ in procs)
+    for p in procs:
+        p.join(60)
+        assert p.exitcode == 0
+    assert all(r[1] for r in res)
+    assert res[0][2] == res[1][2] == [[0.0, 10.0], [1.0, 11.0]]
+
+
+def test_rendezvous_rejects_bad_mappings_before_touching_the_process_group(monkeypatch):
+    import pytest
+    from this_and_that_vdm_amd.dist import RendezvousError, gather_floats, init_ranks
+    with pytest.raises(RendezvousError, match="outside world size"):
+        init_ranks("gloo", 2, 2, 0)
+    monkeypatch.delenv("MASTER_PORT", raising=False)
+    monkeypatch.setenv("MASTER_ADDR", "127.0.0.1")
+    with pytest.raises(RendezvousError, match="MASTER_PORT"):
+        init_ranks("gloo", 0, 2, 0)
+    if not torch.cuda.is_available():                       # the RCCL branch refuses a box without GPUs by name
+        with pytest.raises(RendezvousError, match="needs GPUs"):
+            init_ranks("nccl", 0, 2, 0)
+    assert init_ranks("gloo", 0, 1, 0) == 0.0 and not dist.is_initialized()
+    assert gather_floats([1.5, 2.5], "cpu") == [[1.5, 2.5]]
+
+
+def test_rendezvous_times_out_with_the_cause_in_the_message(monkeypatch):
+    """A rank whose peer never arrives: init_process_group gives up after the timeout and the error names backend, rank and address."""
+    import pytest
+    from this_and_that_vdm_amd.dist import RendezvousError, init_ranks
+    monkeypatch.setenv("MASTER_ADDR", "127.0.0.1")
+    monkeypatch.setenv("MASTER_PORT", str(_free_port()))
+    with pytest.raises(RendezvousError, match=r"init_process_group\('gloo', rank 1/2"):
+        init_ranks("gloo", 1, 2, 1, timeout_s=3)            # rank 1 without a rank 0: nobody hosts the store
+    assert not dist.is_initialized()

@@ -118,17 +118,21 @@ def test_full_size_properties(full):
     assert torch.equal(c.result().cpu(), inp["latents"].float().reshape(c.result().shape))
 
 
-def _two_fused_steps(full, dtype):
+def _two_fused_steps(full, dtype, attention_fp8=False):
     from this_and_that_vdm_amd.svd.denoise import DenoiseLoop
     from this_and_that_vdm_amd.svd.scheduling_euler_discrete import EulerDiscreteScheduler
     unet, cn = _product(full, dtype)
     sched = EulerDiscreteScheduler()
     sched.set_timesteps(25)
-    loop = DenoiseLoop(unet, cn, use_graph=True).begin(**_loop_args(full["inp"], sched.sigmas, sched.timesteps))
-    loop.step()
-    lat1 = loop.result().clone()
-    loop.step()
-    return sched, lat1.cpu(), loop.result().cpu()
+    unet.attention_fp8 = cn.attention_fp8 = attention_fp8
+    try:
+        loop = DenoiseLoop(unet, cn, use_graph=True).begin(**_loop_args(full["inp"], sched.sigmas, sched.timesteps))
+        loop.step()
+        lat1 = loop.result().clone()
+        loop.step()
+        return sched, lat1.cpu(), loop.result().cpu()
+    finally:
+        unet.attention_fp8 = cn.attention_fp8 = False
 
 
 @torch.no_grad()
@@ -184,6 +188,28 @@ def test_full_size_two_steps_match_oracle(full, dtype, rel, cos):
             print(f"full-size VGL, {dtype}, step 1: reference autocast rel-L2 {y['rel_l2']:.3e} (in tol {y['frac_in_tol']:.3f}) | "
                   f"HIP rel-L2 {s['rel_l2']:.3e} (in tol {s['frac_in_tol']:.3f})")
             assert s["rel_l2"] <= 1.25 * y["rel_l2"], (s, y)
+
+
+@torch.no_grad()
+def test_full_size_two_steps_with_fp8_attention_match_oracle(full):
+    """BASELINE config 5's precision mode (``attention_fp8``: spatial self-attention on e4m3 operands, everything else bf16)
+    against the fp32 ORACLE, not against the HIP bf16 step: two fused VGL steps at 32x56 on the fixture's weights and inputs.
+    Limit: relative L2 of the network contribution <= 1.5 x the distance the plain bf16 step measures in the same process
+    (both printed next to the reference's own autocast-bf16 distance), cosine >= 0.9995."""
+    ref, inp = full["ref"], full["inp"]
+    sample = inp["latents"].double()
+    runs = {"bf16": _two_fused_steps(full, torch.bfloat16), "fp8": _two_fused_steps(full, torch.bfloat16, attention_fp8=True)}
+    sched = runs["bf16"][0]
+    y = _reference_16bit_yardstick(torch.bfloat16)
+    assert not torch.equal(runs["bf16"][1], runs["fp8"][1]), "attention_fp8 had no effect"
+    for k in (1, 2):
+        share = float(sched.sigmas[k]) / float(sched.sigmas[0])
+        contrib = lambda z: (z.double().reshape(sample.shape) - sample * share).float()
+        st = {name: err_stats(contrib(r[k]), contrib(ref[f"lat{k}"])) for name, r in runs.items()}
+        print(f"full-size VGL step {k} vs fp32 oracle: bf16 attention rel-L2 {st['bf16']['rel_l2']:.3e} | fp8 attention "
+              f"{st['fp8']['rel_l2']:.3e} (in tol {st['fp8']['frac_in_tol']:.3f}) | reference autocast bf16 (step 1) {y['rel_l2']:.3e}")
+        assert st["fp8"]["ref_absmax"] > 0.1, "degenerate comparison"
+        assert st["fp8"]["rel_l2"] <= 1.5 * st["bf16"]["rel_l2"] and st["fp8"]["cos"] >= 0.9995, (k, st)
 
 
 @pytest.mark.parametrize("dtype,fp8", [(torch.float32, False), (torch.bfloat16, False), (torch.bfloat16, True)])

@@ -408,9 +408,9 @@ def test_layernorm_and_fused_frame_embedding(ops, dtype, c):
 @pytest.mark.parametrize("ln,geglu,m,n,k", [(1, 1, 8192 - 37, 6144 - 16, 128), (1, 0, 8192, 6144 - 48, 192), (0, 1, 8192, 6144, 128),
                                             (0, 0, 8192 - 200, 6144, 320),
                                             (1, 1, 3136, 10240, 1280),      # 12 whole tile rows + a ragged row of 64: ragged tiles last, to the idle CUs
-                                            (0, 0, 3072 + 130, 10240, 256)])  # ragged row of 130 rows: the upper wave row works, the lower skips
+                                            (0, 0, 3072 + 130, 10240, 256)])  # 130 ragged rows: launched in two parts (12 whole tile rows + 130 rows on the tiled kernel)
 def test_gemm_persistent_pingpong_kernel(ops, dtype, ln, geglu, m, n, k):
-    """gemm_pp.hip: tall-and-wide Linear problems without per-row epilogue operands (>= 3 rounds of 256 x 256 tiles per CU) run on
+    """gemm_pp.hip: tall-and-wide Linear problems without per-row epilogue operands (>= 460 tiles of 256 x 256: ~1.8 rounds of the 256 CUs) run on
     the persistent ping-pong kernel -- fused LayerNorm statistics, bias, GEGLU or plain 16-bit output, ragged last tile rows and
     columns.  Checked against torch fp32 and against the tiled kernel on the same operands (forced tile configuration)."""
     from this_and_that_vdm_amd.packing import fold_layernorm, pack_geglu, zero_sum_round
@@ -453,6 +453,62 @@ def test_gemm_persistent_pingpong_kernel(ops, dtype, ln, geglu, m, n, k):
     torch.testing.assert_close(out.float().cpu(), ref, rtol=rt, atol=at)
     # vs the tiled kernel on the same operands: the same arithmetic up to fp32 summation order / one fused multiply-add
     torch.testing.assert_close(out.float(), tiled.float(), rtol=tol["rtol"], atol=tol["atol"])
+
+
+def _kernel_name(ops, *a, **kw):
+    ops.PROFILE = []
+    ops.gemm(*a, **kw)
+    torch.cuda.synchronize()
+    name = ops.PROFILE[0][0]
+    ops.PROFILE = None
+    return name
+
+
+@pytest.mark.parametrize("dtype", DTYPES16)
+@pytest.mark.parametrize("variant", ["no_bias", "strided_a", "wide_out", "split_tail_wide_out", "vae_vt"])
+def test_gemm_persistent_pingpong_operand_variants(ops, dtype, variant):
+    """Reachable variants of the persistent kernel beyond contiguous-A-with-bias: bias == NULL (the strip's bias slot is filled
+    by the out-of-range zero fill of the LDS-DMA), a row-strided A view (lda0 != k0: the live-class projections run on
+    t[cls::cb]), an output with ldo > n, the two-part launch (whole tile rows on the persistent kernel, ragged rows on the
+    tiled kernel) into such an output, and the temporal VAE decoder's V^T projection (m = 512 channels, n = frames * h*w
+    tokens >= 120 k, no bias: autoencoder_kl_temporal_decoder.py).  Each against torch fp32 and the tiled kernel."""
+    lib = ops._lib.load()
+    kw = {}
+    if variant == "vae_vt":
+        m, n, k = 512, 14 * 8960, 512                                # 14 frames x (80 x 112) tokens
+    elif variant == "split_tail_wide_out":
+        m, n, k = 3136, 10240, 320
+    else:
+        m, n, k = 8192 - 56, 6144, 192
+    w = rnd(n, k, dtype=dtype, seed=2, scale=k ** -0.5).cuda()
+    if variant == "strided_a":
+        big = rnd(2 * m, k, dtype=dtype, seed=1).cuda()
+        x = big[1::2]
+        assert x.stride(0) == 2 * k
+    else:
+        x = rnd(m, k, dtype=dtype, seed=1).cuda()
+    bias = None if variant in ("no_bias", "vae_vt") else rnd(n, dtype=torch.float32, seed=3)
+    if bias is not None:
+        kw["bias"] = bias.cuda()
+    out = None
+    if variant in ("wide_out", "split_tail_wide_out"):
+        store = torch.full((m + 4, n + 72), 5.0, dtype=dtype, device="cuda")
+        out = store[:m, 8:8 + n]
+        assert out.stride(0) == n + 72
+    ref = x.float().cpu() @ w.float().cpu().T + (bias if bias is not None else 0.0)
+    name = _kernel_name(ops, x, w, out=out, **kw)
+    assert name.startswith("gemm_pp_kernel<"), name
+    got = ops.gemm(x, w, out=out, **kw)
+    lib.tt_gemm_set_tile_override(11)
+    try:
+        tiled = ops.gemm(x, w, **kw)
+    finally:
+        lib.tt_gemm_set_tile_override(-1)
+    close(got, ref, dtype, scale=2.0)
+    tol = TOL[dtype]
+    torch.testing.assert_close(got.float(), tiled.float(), rtol=tol["rtol"], atol=tol["atol"])
+    if out is not None:                                              # nothing outside the [m, n] window was written
+        assert (store[m:] == 5.0).all() and (store[:, :8] == 5.0).all() and (store[:, 8 + n:] == 5.0).all()
 
 
 @pytest.mark.parametrize("dtype", DTYPES)

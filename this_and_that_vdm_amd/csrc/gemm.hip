@@ -151,9 +151,11 @@ bool sq320_ok(const TtGemmArgs* a) {
 // gets about two or more 256 x 256 tiles and the last round of tiles is nearly full: the GEGLU projections at the three finest UNet
 // levels (1960 / 980 / 480 tiles).  A problem whose row count is not a multiple of 256 and that only qualifies without its
 // ragged last tile row is launched in two parts -- whole tile rows on the persistent kernel, the remaining < 256 rows on the tiled
-// kernel (3136 rows: 480 tiles = 1.9 rounds + 64 rows, instead of 520 tiles = 3 rounds; a ragged tile costs the persistent kernel
-// a whole tile time even with its all-zero MFMAs skipped, and cutting tiles along K stream-K fashion costs more in partial-tile
-// traffic than it saves: DESIGN.md section 6.0).  TT_GEMM_PP=0 keeps everything on the tiled kernels (A/B).
+// kernel (3136 rows: 480 tiles = 1.9 rounds + 64 rows, instead of 520 tiles = 3 rounds; the persistent kernel has no short cut for
+// a ragged tile -- its out-of-range rows are zero-filled by the DMA bounds check and multiplied like any others, so it costs a
+// whole tile time -- and cutting tiles along K stream-K fashion costs more in partial-tile traffic than it saves: DESIGN.md
+// section 6.0).  TT_GEMM_PP=0 keeps everything on the tiled kernels (A/B).
+// The constants below (256 CUs, one workgroup per CU) are MI355X in SPX mode: the only target of this library (gfx950, tt_target_arch).
 static int g_pp = -1;
 bool pp_ok(const TtGemmArgs* a) {
   if (g_pp < 0) { const char* e = getenv("TT_GEMM_PP"); g_pp = e ? atoi(e) : 1; }

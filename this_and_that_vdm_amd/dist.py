@@ -10,6 +10,72 @@ import torch
 import torch.distributed as dist
 
 
+class RendezvousError(RuntimeError):
+    """The N > 1 start-up failed (bad rank / device mapping, process-group init, or the first collective)."""
+
+
+def init_ranks(backend: str, rank: int, world: int, local_rank: int, device=None, timeout_s: float = 180.0) -> float:
+    """Fail-loud start-up of the one-process-per-GPU job: checks the rank / LOCAL_RANK / device mapping BEFORE touching the
+    process group, initialises it with a finite timeout, and proves the transport with a 1-element broadcast + all-reduce
+    before any large collective (the 3 GB weight broadcast) is queued on it.  Raises RendezvousError with the cause in its
+    text; returns the seconds spent.  ``backend`` "nccl" is RCCL on ROCm (one GPU per rank), "gloo" the CPU tests."""
+    import datetime
+    import os
+    t0 = time.perf_counter()
+    if world < 1 or not (0 <= rank < world):
+        raise RendezvousError(f"rank {rank} outside world size {world} (RANK / WORLD_SIZE from the launcher)")
+    if backend == "nccl":
+        if not torch.cuda.is_available():
+            raise RendezvousError("backend nccl (RCCL) needs GPUs: torch.cuda.is_available() is False")
+        ndev = torch.cuda.device_count()
+        if not (0 <= local_rank < ndev):
+            raise RendezvousError(f"LOCAL_RANK {local_rank} has no GPU: {ndev} device(s) visible to rank {rank} "
+                                  f"(HIP_VISIBLE_DEVICES={os.environ.get('HIP_VISIBLE_DEVICES')!r}, "
+                                  f"ROCR_VISIBLE_DEVICES={os.environ.get('ROCR_VISIBLE_DEVICES')!r}); one rank per GPU is required")
+        if os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0") != "0":
+            raise RendezvousError("HSA_ENABLE_IPC_MODE_LEGACY must be 0 for RCCL on this host (dmabuf IPC only); "
+                                  f"found {os.environ['HSA_ENABLE_IPC_MODE_LEGACY']!r}")
+    for var in ("MASTER_ADDR", "MASTER_PORT"):
+        if world > 1 and not os.environ.get(var):
+            raise RendezvousError(f"{var} is not set: launch with torch.distributed.run --master-addr 127.0.0.1 --master-port P")
+    if world == 1:
+        return 0.0
+    kw = dict(rank=rank, world_size=world, timeout=datetime.timedelta(seconds=timeout_s))
+    if backend == "nccl" and device is not None:
+        kw["device_id"] = device
+    try:
+        dist.init_process_group(backend, **kw)
+    except Exception as e:                                   # noqa: BLE001 -- every cause is reported the same way
+        raise RendezvousError(f"init_process_group({backend!r}, rank {rank}/{world}, {os.environ.get('MASTER_ADDR')}:"
+                              f"{os.environ.get('MASTER_PORT')}, timeout {timeout_s:.0f} s) failed: {type(e).__name__}: {e}") from e
+    try:
+        dev = device if backend == "nccl" else "cpu"
+        probe = torch.full((1,), float(rank + 1) if rank == 0 else -1.0, dtype=torch.float32, device=dev)
+        dist.broadcast(probe, src=0)
+        ones = torch.ones(1, dtype=torch.float32, device=dev)
+        dist.all_reduce(ones)
+        if backend == "nccl":
+            torch.cuda.synchronize()
+        if float(probe.item()) != 1.0 or float(ones.item()) != float(world):
+            raise RendezvousError(f"first collective returned wrong data on rank {rank}: broadcast {float(probe.item())} "
+                                  f"(expected 1.0), all-reduce {float(ones.item())} (expected {world})")
+    except RendezvousError:
+        raise
+    except Exception as e:                                   # noqa: BLE001
+        raise RendezvousError(f"first collective over {backend!r} failed on rank {rank}/{world}: {type(e).__name__}: {e}") from e
+    return time.perf_counter() - t0
+
+
+def gather_floats(values, device) -> list:
+    """values (a list of floats of this rank) from every rank: [[rank 0's], [rank 1's], ...]; [values] when not distributed."""
+    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size() == 1:
+        return [list(values)]
+    mine = torch.tensor(list(values), dtype=torch.float64, device=device)
+    allv = [torch.zeros_like(mine) for _ in range(dist.get_world_size())]
+    dist.all_gather(allv, mine)
+    return [[float(x) for x in v] for v in allv]
+
+
 def flat_param_buffer(model: torch.nn.Module) -> torch.Tensor:
     """Re-home all parameters as views of ONE flat buffer (same dtype) so a model is broadcast by a single,
     large collective (3 GB for the UNet in bf16) instead of ~1400 small ones."""

@@ -294,13 +294,22 @@ def add_rowvec(x, rowvec, rows_per_vec: int, nvec: int, out=None):
 
 
 def softmax_rows(x, dtype, cols: Optional[int] = None, out=None):
-    """row softmax of fp32 scores x[:, :cols] -> `dtype`, columns cols..out.shape[1] zeroed (padding for a following GEMM)."""
+    """row softmax of fp32 scores x[:, :cols] -> `dtype`, columns cols..out.shape[1] zeroed (padding for a following GEMM).
+    Contract of tt_softmax_rows: the kernel reads whole float4 quads up to round_up(cols, 8), so the score rows must be
+    at least that long in memory (x.stride(0) >= round_up(cols, 8); the values beyond `cols` are ignored) and the output
+    has round_up(cols, 8) or more columns."""
     lib = _lib.load()
     assert x.dtype == torch.float32 and x.stride(1) == 1
     rows = x.shape[0]
     cols = x.shape[1] if cols is None else cols
+    cols_pad = (cols + 7) // 8 * 8
+    if x.stride(0) < cols_pad:
+        raise ValueError(f"softmax_rows: score rows of {cols} columns need a row stride >= {cols_pad} floats (got {x.stride(0)}): "
+                         "allocate the score buffer with its column count rounded up to 8")
     if out is None:
-        out = torch.empty((rows, (cols + 7) // 8 * 8), dtype=dtype, device=x.device)
+        out = torch.empty((rows, cols_pad), dtype=dtype, device=x.device)
+    if out.shape[1] < cols_pad:
+        raise ValueError(f"softmax_rows: output needs >= {cols_pad} columns, got {out.shape[1]}")
     check(lib.tt_softmax_rows(_p(x), x.stride(0), rows, cols, _p(out), out.stride(0), out.shape[1], _code(dtype), _stream()),
           "tt_softmax_rows")
     return out

@@ -222,7 +222,7 @@ class ResnetBlock2D(_Packable):
         if fused:
             st1 = ops.groupnorm_stats(x0, x1, g.n, g.hw, 1, self.g1, self.be1, self.eps)
             hmid = ops.conv3x3(x0, x1, self.w1, g.n, g.h, g.w, gn=st1, silu=True, bias=self.b1, rowvec=film,
-                               rowvec_rows=g.frames * g.hw)
+                               rowvec_rows=g.frames * g.hw if film is not None else 0)
         else:
             a = ops.groupnorm(x0, x1, g.n, g.hw, 1, self.g1, self.be1, self.eps, True)
             hmid = ops.gemm(a, self.w1, mode=1, conv=conv, bias=self.b1, rowvec=film, rowvec_rows=g.frames * g.hw if film is not None else 0)
