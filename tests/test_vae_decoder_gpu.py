@@ -50,14 +50,15 @@ def test_decoder_matches_oracle(dtype, rel):
         assert_north_star(alone, ref[3:], "second video decoded alone")
 
 
-@pytest.mark.parametrize("dtype,rel", [(torch.float32, 1e-4), (torch.float16, 6e-3), (torch.bfloat16, 4.5e-2)])
+@pytest.mark.parametrize("dtype,rel", [(torch.float32, 1e-4), (torch.float16, 4.6e-3), (torch.bfloat16, 3.7e-2)])
 @torch.no_grad()
 def test_decoder_at_the_shipped_widths_matches_oracle(dtype, rel):
     """The decoder as SVD ships it -- block_out_channels (128, 256, 512, 512): the mid-block attention is ONE head of d = 512
     over L = h*w tokens (here 16x28 = 448: the per-frame score / softmax / PV loop with an fp32 score buffer), GroupNorm over
     128..512 channels up to 128x224 pixels, conv_out + the 3-tap frame conv -- on a small spatial case (2 frames of 16x28
     latents -> 128x224 pixels) against oracle/vae.py on identical weights.  TT_F32: every element inside rtol 1e-3 / atol 1e-4;
-    16-bit storage: relative L2 (limits = 2 x the values measured on MI355X: fp16 3e-3, bf16 2.2e-2), cosine >= 0.999."""
+    16-bit storage: relative L2 (limits = 2 x the values measured on MI355X: fp16 2.27e-3, bf16 1.84e-2; TT_F32 measured 5.3e-6),
+    cosine >= 0.999."""
     if not torch.cuda.is_available():
         pytest.skip("needs a GPU")
     threads = torch.get_num_threads()
