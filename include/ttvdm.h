@@ -112,6 +112,11 @@ int tt_gemm_set_tile_override(int32_t cfg);
  * the persistent W-in-registers streaming kernel.  Off by default (faster alone, slower next to a concurrent branch);
  * also settable by TT_GEMM_SQ320=1. */
 int tt_gemm_set_streaming_square(int32_t on);
+/* tuning knob: 0 keeps the problems of the finest UNet level (N = 320 t, >= 160 row tiles of 256: the ResnetBlock2D / temporal convs,
+ * shortcuts, proj_in/out, to_out, FF2, LayerNorm-folded Q projections -- svd/diffusion_arch/unet_3d_blocks.py:2094,2212,2311,
+ * svd/diffusion_arch/transformer_temporal.py:323-376) on the tiled kernels instead of the 256 x 320 big-tile kernel (gemm_w320.hip);
+ * 1 (default) routes them there.  Also settable by TT_GEMM_W320=0.  For A/B measurements and tests. */
+int tt_gemm_set_big_tile(int32_t on);
 
 /* ------------------------------------------------------------------------------------------------
  * tt_conv3x3: Conv2d 3x3 / stride 1 / pad 1 with the GroupNorm (+SiLU) of its INPUT fused in -- the ResnetBlock2D convs

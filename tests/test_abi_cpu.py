@@ -79,3 +79,47 @@ def test_gemm_dispatch_rules_of_the_persistent_kernel(lib):
     assert plan(50176, 2560, 320, f32)[0][:4] != pp                        # fp32 storage
     assert plan(50176, 2560, 320, bf16, residual=1)[0][:4] != pp           # per-row epilogue operand (any non-null pointer)
     assert plan(50176, 2560, 328, bf16)[0][:4] != pp                       # K not a multiple of 64
+
+
+def test_gemm_dispatch_rules_of_the_big_tile_kernel(lib):
+    """tt_gemm_plan, host-only: which problems go to gemm_w320_kernel (reported as tile 256 x 320 x 64, stages 0, 4 x 2 waves):
+    16-bit problems with N = 320 t whose 256-row tiles fill >= 70 % of the CU x round slots -- Linear (also with the LayerNorm fold,
+    two sources, residual / blend / row vector), conv3x3 stride 1, temporal conv; the knob tt_gemm_set_big_tile(0) turns it off."""
+    import ctypes as C
+    from this_and_that_vdm_amd import ops
+
+    def plan(m, n, k, dtype=ops.TT_BF16, **kw):
+        g = _lib.TtGemmArgs()
+        g.m, g.n, g.k0, g.mode, g.dtype = m, n, k, 0, dtype
+        g.lda0, g.ldw, g.ldo = k, k, n
+        g.ln_eps = 1e-5
+        for name, v in kw.items():
+            setattr(g, name, v)
+        cfg = (C.c_int32 * 7)()
+        assert lib.tt_gemm_plan(C.byref(g), cfg) == 0
+        return list(cfg), lib.tt_gemm_ws_bytes(C.byref(g))
+
+    w320 = [256, 320, 64, 0, 4, 2, 1]
+    conv = dict(mode=1, nimg=28, hin=32, win=56, hout=32, wout=56, stride=1, upsample=0)
+    assert plan(50176, 320, 1280, residual=1, ld_res=320) == (w320, 0)                   # FF2 at 32x56
+    assert plan(50176, 320, 320, residual=1, ld_res=320, blend=1, ld_blend=320)[0] == w320
+    assert plan(50176, 960, 320, ln_fold=1)[0] == w320                                   # LayerNorm-folded QKV: 588 tiles, 77 %
+    assert plan(50176, 320, 320, k1=320, lda1=320, **conv)[0] == w320                    # conv over a skip concat
+    assert plan(50176, 320, 320, mode=2, frames=14, hw=1792)[0] == w320
+    assert plan(200704, 320, 320)[0] == w320                                             # 64x112 latents: 784 tiles
+    assert plan(50176, 320, 320, rowvec=1, rowvec_rows=1792, ld_rowvec=320)[0] == w320
+    assert plan(50176, 320, 320, rowvec=1, rowvec_rows=16, ld_rowvec=320)[0] != w320     # row-vector groups shorter than a fragment row
+    assert plan(25088, 320, 320)[0] != w320                                              # 98 tiles
+    assert plan(50176, 640, 320, geglu=1)[0] != w320
+    assert plan(50176, 320, 320, dtype=ops.TT_F32)[0] != w320
+    assert plan(50176, 320, 72)[0] != w320                                               # K % 64
+    assert plan(50176, 320, 320, **dict(conv, stride=2, hin=64, win=112))[0] != w320
+    assert plan(50176, 320, 320, **dict(conv, upsample=1, hin=16, win=28))[0] != w320
+    assert plan(50176, 320, 320, out_f32=1)[0] != w320
+    assert plan(50176, 2560, 320, ln_fold=1, geglu=1)[0][:4] == [256, 256, 64, 0]        # the GEGLU projections stay on gemm_pp
+    try:
+        assert lib.tt_gemm_set_big_tile(0) == 0
+        assert plan(50176, 320, 1280)[0] != w320
+    finally:
+        lib.tt_gemm_set_big_tile(1)
+    assert plan(50176, 320, 1280)[0] == w320

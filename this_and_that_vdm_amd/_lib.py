@@ -64,6 +64,7 @@ SIGNATURES = {
     "tt_last_error": (C.c_char_p, []),
     "tt_gemm": (C.c_int, [C.POINTER(TtGemmArgs), _vp]),
     "tt_gemm_set_streaming_square": (C.c_int, [C.c_int32]),
+    "tt_gemm_set_big_tile": (C.c_int, [C.c_int32]),
     "tt_gemm_plan": (C.c_int, [C.POINTER(TtGemmArgs), C.POINTER(C.c_int32)]),
     "tt_gemm_set_tile_override": (C.c_int, [_i32]),
     "tt_gemm_ws_bytes": (_sz, [C.POINTER(TtGemmArgs)]),

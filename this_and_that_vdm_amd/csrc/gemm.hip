@@ -26,6 +26,8 @@ void launch_sq320_bf16(const GemmP& p, hipStream_t st);
 void launch_sq320_f16(const GemmP& p, hipStream_t st);
 void launch_pp_bf16(GemmP& p, hipStream_t st);         // gemm_pp.hip: persistent 256 x 256 x 64 ping-pong kernel
 void launch_pp_f16(GemmP& p, hipStream_t st);
+void launch_w320_bf16(GemmP& p, hipStream_t st);       // gemm_w320.hip: 256 x 320 x 64 tiles for N = 320 t at the finest UNet level
+void launch_w320_f16(GemmP& p, hipStream_t st);
 }
 using namespace ttg;
 
@@ -166,6 +168,27 @@ bool pp_ok(const TtGemmArgs* a) {
   const long rounds = (tiles + 255) / 256;
   return tiles >= 460 && tiles * 10 >= rounds * 256 * 9;      // ~2 rounds of tiles per CU or more, last round >= 90 % full on average
 }
+// The 256 x 320 big-tile kernel (gemm_w320.hip) takes 16-bit problems whose output width is a multiple of 320 and whose row count
+// fills most of a round of 256 CUs with 256-row tiles (the finest UNet level: 50176 rows = 196 tiles): Linear (one or two sources,
+// optional LayerNorm fold of the A rows), conv3x3 stride 1 and the temporal conv, with bias / scale / row vector (groups of >= 32
+// rows) / residual / AlphaBlender epilogues.  TT_GEMM_W320=0 keeps them on the tiled kernels (A/B).
+static int g_w320 = -1;
+extern "C" int tt_gemm_set_big_tile(int32_t on) {
+  g_w320 = on ? 1 : 0;
+  return TT_OK;
+}
+bool w320_ok(const TtGemmArgs* a) {
+  if (g_w320 < 0) { const char* e = getenv("TT_GEMM_W320"); g_w320 = e ? atoi(e) : 1; }
+  if (!g_w320 || forced_cfg() >= 0 || a->dtype == TT_F32 || a->n % 320 || (a->k0 & 63) || (a->k1 & 63) || (a->mode == 1 ? 9 : a->mode == 2 ? 3 : 1) * (a->k0 + a->k1) < 128 || a->geglu ||
+      a->out_fp8 || a->out_f32 || a->out_col_hw || a->ln_fold > 1 || (a->ln_fold && (a->mode != 0 || a->k1)))
+    return false;
+  if (a->mode == 1 && (a->stride != 1 || a->upsample || a->hin != a->hout || a->win != a->wout || a->win >= 32768 || a->hin >= 32768)) return false;
+  if (a->rowvec && a->rowvec_rows < 32) return false;
+  if ((a->ldo & 3) || (a->residual && (a->ld_res & 3)) || (a->blend && (a->ld_blend & 3))) return false;
+  const long tiles = (long)ceil_div(a->m, 256) * (a->n / 320);
+  const long rounds = (tiles + 255) / 256;
+  return tiles >= 160 && tiles * 100 >= rounds * 256 * 70;       // >= 70 % of the CU x round slots busy (196 / 392 / 588 / 784 tiles: 77 %)
+}
 // rows the persistent kernel takes when the problem is launched in two parts (0: one launch)
 static int pp_split_rows(const TtGemmArgs* a) {
   if ((a->m & 255) == 0 || a->m < 512 || pp_ok(a)) return 0;
@@ -204,6 +227,10 @@ extern "C" int tt_gemm_plan(const TtGemmArgs* a, int32_t cfg[7]) {
     cfg[0] = 256; cfg[1] = 256; cfg[2] = 64; cfg[3] = 0; cfg[4] = 2; cfg[5] = 4; cfg[6] = 1;
     return TT_OK;
   }
+  if (w320_ok(a)) {                               // gemm_w320_kernel<dtype, mode, ln>: 256 x 320 tiles, 4 x 2 waves, stages = 0
+    cfg[0] = 256; cfg[1] = 320; cfg[2] = 64; cfg[3] = 0; cfg[4] = 4; cfg[5] = 2; cfg[6] = 1;
+    return TT_OK;
+  }
   if (sq320_ok(a)) {          // the streaming kernel for the 320 x 320 linears: 32-row tiles, ring depth 3 (5 without residual)
     cfg[0] = SQ_ROWS; cfg[1] = SQ_N; cfg[2] = SQ_K; cfg[3] = a->residual ? 3 : 5; cfg[4] = 1; cfg[5] = SQ_WAVES; cfg[6] = 1;
     return TT_OK;
@@ -220,6 +247,7 @@ extern "C" int tt_gemm_plan(const TtGemmArgs* a, int32_t cfg[7]) {
 extern "C" size_t tt_gemm_ws_bytes(const TtGemmArgs* a) {
   if (!a || a->m <= 0 || a->n <= 0) return 0;
   if (pp_ok(a)) return 0;
+  if (!pp_split_rows(a) && w320_ok(a)) return 0;
   if (const int rows = pp_split_rows(a)) { TtGemmArgs head, tail; pp_split(a, rows, &head, &tail); return tt_gemm_ws_bytes(&tail); }
   const Plan pl = plan_for(a);
   return pl.splitk > 1 ? (size_t)pl.splitk * a->m * a->n * sizeof(float) : 0;
@@ -293,6 +321,12 @@ extern "C" int tt_gemm(const TtGemmArgs* a, tt_stream_t stream) {
   if (pp_ok(a)) {
     p.splitk = 1; p.ws = nullptr; p.ws_bytes = 0; p.group_m_override = group_m_override(); p.group_m = 1;
     if (a->dtype == TT_BF16) launch_pp_bf16(p, st); else launch_pp_f16(p, st);
+    TT_CHECK_LAUNCH("tt_gemm");
+    return TT_OK;
+  }
+  if (w320_ok(a)) {
+    p.splitk = 1; p.ws = nullptr; p.ws_bytes = 0; p.group_m_override = 0; p.group_m = 1;
+    if (a->dtype == TT_BF16) launch_w320_bf16(p, st); else launch_w320_f16(p, st);
     TT_CHECK_LAUNCH("tt_gemm");
     return TT_OK;
   }

@@ -1,0 +1,378 @@
+// gemm_w320: the 256 x 320 x 64 big-tile member of the tt_gemm family (round 4), for the problems of the FINEST UNet level whose
+// output is 320 channels wide (or a multiple): the ResnetBlock2D 3x3 convs, the (3,1,1) temporal convs, the 1x1 shortcuts over the
+// skip concat, proj_in / proj_out, to_out, FF2 and the LayerNorm-folded Q projection at 32x56 latents (M = 28 x 1792 = 50176 rows =
+// exactly 196 row tiles) -- reference svd/diffusion_arch/unet_3d_blocks.py:2094,2212,2311 (up blocks) and
+// svd/diffusion_arch/transformer_temporal.py:323-376.  The tiled template serves them with 128 x 160 tiles (wave tile 32 x 160) whose
+// K step needs 57 bytes of LDS fill per MFMA clock -- more than the ~54 B/clk/CU an LDS-DMA stream delivers (tools/dma_shape_test.hip),
+// so it runs at 280-800 TFLOP/s; N = 320 does not tile by the persistent kernel's 256 columns either (gemm_pp.hip: 37 % column waste).
+//
+// Structure:
+//   * 256 x 320 output tile (full width at N = 320: no column waste, 28.6 B of fill per MFMA clock), ONE tile per workgroup
+//     (196 tiles: one round on 196 of the 256 CUs; the other CUs stay free for the concurrent branch of the step graph),
+//     8 waves as 4 (rows) x 2 (columns): wave tile 64 x 160 = 2 x 5 MFMA fragments of 32 x 32 (160 accumulator registers);
+//   * K slabs of 64 elements = 128-byte rows (full cache lines per LDS-DMA piece); two 72 KiB slots, each the A region (256 rows,
+//     32 KiB) and five W regions (W_j = the j-th 32-column fragment of BOTH wave columns, 64 rows, 8 KiB);
+//   * a slab is consumed in FIVE phases of 8 MFMAs: phase j multiplies the A half-tile of the wave (read once in phase 0 and
+//     kept in 32 registers) with W_j.  Every region is read exactly once per slab and re-staged ONE phase after its read for
+//     slab s+2 (two pieces per thread and phase), so 8 pieces per thread are always in flight and the only counted wait is
+//     vmcnt(8) at the end of phase 4;
+//   * the two groups of four waves (one of each per SIMD) run one barrier apart as in gemm_pp.hip: one issues its 8 MFMAs while
+//     the other reads fragments and issues DMA;
+//   * the producer walks (tap, source, k) like the tiled template: conv3x3 (stride 1) and temporal-conv taps shift the row
+//     offsets of the 4 A pieces of a thread (recomputed once per tap), halo / ragged rows read zeros through the descriptor
+//     bounds check, two channel sources implement the skip concat;
+//   * epilogue after the K loop in the (then free) ring: accumulators transposed through a wave-private 8 KiB fp32 strip, every
+//     load / store instruction covers 4 rows x 128 contiguous bytes; bias, scale, FiLM / frame-position row vector, residual,
+//     AlphaBlender, 1/sigma of the fused LayerNorm (statistics gathered from the A fragments in phase 1's read interval).
+#include <stdlib.h>
+#include <type_traits>
+#include "gemm_kernel.h"
+
+namespace ttg {
+
+template <int N> __device__ __forceinline__ void w3_wait_vm() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
+
+template <typename Tag, int MODE, int LNROWS>
+__global__ __launch_bounds__(512, 2) void gemm_w320_kernel(const GemmP p) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  typedef typename Elem<Tag>::quad_t quad_t;
+  constexpr int BM = 256, BN = 320, ES = 2, CPR = 8, FM = 2, FN = 5;
+  constexpr int A_BYTES = 32768, WJ = 8192, SLOT = A_BYTES + FN * WJ;          // 73728 bytes per slot
+  static_assert(Elem<Tag>::ES == 2, "16-bit storage types only");
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int grp = wid >> 2, wc = wid >> 2, wr = wid & 3;
+  const int l31 = lane & 31, hi = lane >> 5;
+
+  // XCD-contiguous tile order (gemm_kernel.h): neighbouring row tiles (conv halos) and the column tiles of one row share an L2
+  int bid = blockIdx.x;
+  {
+    const int nwg = gridDim.x, q = nwg >> 3, r = nwg & 7, xcd = bid & 7, idx = bid >> 3;
+    bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
+  }
+  const int tile_m = bid / p.tiles_n, tile_n = bid - tile_m * p.tiles_n;
+  const int m0 = tile_m * BM, n0 = tile_n * BN;
+  const int S = p.kt_total;                                                    // slabs: taps * (k0 + k1) / 64
+
+  const __amdgpu_buffer_rsrc_t ra0 = make_rsrc(p.a0, p.a0_bytes);
+  const __amdgpu_buffer_rsrc_t ra1 = make_rsrc(p.a1 ? p.a1 : p.a0, p.a1_bytes);
+  const __amdgpu_buffer_rsrc_t rw = make_rsrc(p.w, p.w_bytes);
+
+  // ---- producer: thread t stages 16-byte chunk (t & 7) of row (t >> 3) of every 64-row pass: 4 passes of A, one per W region
+  const int rr = tid >> 3, ch = (tid & 7) ^ tile_swz<CPR>(rr);                 // source chunk (the swizzle only depends on rr mod 16)
+  const int w_v = (int)(((long)(n0 + (rr >> 5) * 160 + (rr & 31)) * p.ldw + ch * 8) * ES);     // n % 320 == 0: always in range
+  const int w_jstride = __builtin_amdgcn_readfirstlane((int)(32 * p.ldw * ES));
+  int a_pos[4];                                                                // MODE 1: y << 16 | x ; MODE 2: frame index
+  int a_off[4];                                                                // byte offsets of the producer's (tap, source)
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    a_pos[i] = 0;
+    const int g = min(m0 + i * 64 + rr, p.m - 1);
+    if constexpr (MODE == 1) {
+      const int hw = p.hout * p.wout, rem = g - (g / hw) * hw, y = rem / p.wout;
+      a_pos[i] = (y << 16) | (rem - y * p.wout);
+    } else if constexpr (MODE == 2) {
+      a_pos[i] = (g / p.hw) % p.frames;
+    }
+  }
+  int p_tap = 0, p_src = 0, p_kc = 0, p_slab = 0;
+  auto refresh = [&]() {
+    const long lda = p_src ? p.lda1 : p.lda0;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int g = m0 + i * 64 + rr;
+      bool ok = g < p.m;
+      long row = g;
+      if constexpr (MODE == 1) {
+        const int dy = p_tap / 3 - 1, dx = p_tap - (dy + 1) * 3 - 1;
+        const int y = (a_pos[i] >> 16) + dy, x = (a_pos[i] & 0xffff) + dx;
+        ok = ok && (unsigned)y < (unsigned)p.hin && (unsigned)x < (unsigned)p.win;
+        row = (long)g + dy * p.win + dx;
+      } else if constexpr (MODE == 2) {
+        ok = ok && (unsigned)(a_pos[i] + p_tap - 1) < (unsigned)p.frames;
+        row = (long)g + (long)(p_tap - 1) * p.hw;
+      }
+      a_off[i] = ok ? (int)((row * lda + ch * 8) * ES) : kInv;
+    }
+  };
+  refresh();
+  int p_soff_a = 0, p_soff_w = 0;
+  bool p_ok = S > 0;
+  auto advance = [&]() {                    // the producer moves to the next slab (called after the piece that closes a slab: W_4)
+    if (++p_kc == (p_src ? p.nk1 : p.nk0)) {
+      p_kc = 0;
+      if (p_src == 0 && p.nk1 > 0) p_src = 1; else { p_src = 0; ++p_tap; }
+      if (MODE != 0 || p.nk1 > 0) refresh();
+    }
+    ++p_slab;
+    p_ok = p_slab < S;
+    p_soff_a = __builtin_amdgcn_readfirstlane(p_kc * 64 * ES);
+    p_soff_w = __builtin_amdgcn_readfirstlane((int)(((long)p_tap * (p.k0 + p.k1) + (p_src ? p.k0 : 0) + p_kc * 64) * ES));
+  };
+  auto stage_a = [&](int slot, auto i_tag) {
+    constexpr int I = decltype(i_tag)::value;
+    char* dst = smem + slot * SLOT + I * 8192 + wid * 1024;
+    const int v = p_ok ? a_off[I] : kInv;
+    if (__builtin_amdgcn_readfirstlane(p_src))
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(ra1, (__attribute__((address_space(3))) void*)dst, 16, v, p_soff_a, 0, 0);
+    else
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(ra0, (__attribute__((address_space(3))) void*)dst, 16, v, p_soff_a, 0, 0);
+  };
+  auto stage_w = [&](int slot, auto j_tag) {
+    constexpr int J = decltype(j_tag)::value;
+    char* dst = smem + slot * SLOT + A_BYTES + J * WJ + wid * 1024;
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(rw, (__attribute__((address_space(3))) void*)dst, 16, p_ok ? w_v : kInv,
+                                             p_soff_w + J * w_jstride, 0, 0);
+  };
+  using C0 = std::integral_constant<int, 0>; using C1 = std::integral_constant<int, 1>; using C2 = std::integral_constant<int, 2>;
+  using C3 = std::integral_constant<int, 3>; using C4 = std::integral_constant<int, 4>;
+
+  f32x16_t acc[FM][FN];
+#pragma unroll
+  for (int i = 0; i < FM; ++i)
+#pragma unroll
+    for (int j = 0; j < FN; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+  float ln_s[FM], ln_q[FM];
+#pragma unroll
+  for (int i = 0; i < FM; ++i) ln_s[i] = ln_q[i] = 0.f;
+
+  // ---- consumer: fragment addresses inside a slot.  A fragment i: rows wr*64 + i*32 + l31 (+4096 bytes per i: same swizzle);
+  // W fragment j: region j, rows wc*32 + l31 (+8192 bytes per j)
+  const unsigned lds_base = lds_addr(smem);
+  unsigned a_addr[4], b_addr[4];
+  {
+    const int ar = wr * 64 + l31, br = wc * 32 + l31;
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) {
+      a_addr[ks] = ar * 128 + (((ks * 2 + hi) ^ tile_swz<CPR>(ar)) << 4);
+      b_addr[ks] = A_BYTES + br * 128 + (((ks * 2 + hi) ^ tile_swz<CPR>(br)) << 4);
+    }
+  }
+  raw_u32x4_t af[FM][4], bf[4];
+  auto read_a = [&](unsigned sb) {
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) {
+      af[0][ks] = lds_read16_raw_off<0>(sb + a_addr[ks]);
+      af[1][ks] = lds_read16_raw_off<4096>(sb + a_addr[ks]);
+    }
+  };
+  auto read_b = [&](unsigned sb, auto j_tag) {
+    constexpr int J = decltype(j_tag)::value;
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) bf[ks] = lds_read16_raw_off<J * WJ>(sb + b_addr[ks]);
+  };
+  auto mma = [&](auto j_tag) {
+    constexpr int J = decltype(j_tag)::value;
+    __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks)
+#pragma unroll
+      for (int i = 0; i < FM; ++i)
+        acc[i][J] = Cvt<Tag>::mfma32(make_uint4(bf[ks].x, bf[ks].y, bf[ks].z, bf[ks].w),
+                                     make_uint4(af[i][ks].x, af[i][ks].y, af[i][ks].z, af[i][ks].w), acc[i][J]);
+    __builtin_amdgcn_s_setprio(0);
+  };
+  // LayerNorm sums of the wave's A rows: in the read interval of phase 1 (only 4 W reads to wait for, the A fragments are in
+  // registers), while the other group's wave on this SIMD issues its MFMAs.  Both wave columns hold the same A fragments: each
+  // sums the K steps of its parity and the halves meet in the epilogue.
+  auto stats = [&]() {
+    if constexpr (LNROWS) {
+#pragma unroll
+      for (int ks = 0; ks < 4; ++ks)
+        if ((ks & 1) == wc) {
+#pragma unroll
+          for (int i = 0; i < FM; ++i) ln_stat<Tag>(af[i][ks], ln_s[i], ln_q[i]);
+        }
+      __builtin_amdgcn_sched_barrier(0);
+    }
+  };
+  auto bar = [&]() { __builtin_amdgcn_s_barrier(); asm volatile("" ::: "memory"); };
+
+  // ---- prologue: slab 0 complete (slot 0) + everything of slab 1 but W_4 (slot 1), as the steady state would have issued them
+  stage_w(0, C0{}); stage_a(0, C0{}); stage_w(0, C1{}); stage_a(0, C1{}); stage_w(0, C2{}); stage_a(0, C2{});
+  stage_w(0, C3{}); stage_a(0, C3{}); stage_w(0, C4{});
+  advance();
+  stage_w(1, C0{}); stage_a(1, C0{}); stage_w(1, C1{}); stage_a(1, C1{}); stage_w(1, C2{}); stage_a(1, C2{});
+  stage_w(1, C3{}); stage_a(1, C3{});
+  w3_wait_vm<8>();
+  bar();
+  if (grp == 1) bar();                                       // group 1 runs one barrier behind group 0
+
+  for (int s = 0; s < S; ++s) {
+    const int slot = s & 1;
+    const unsigned sb = lds_base + slot * SLOT;
+    // ---- phase 0: A (kept for the slab) + W_0 ; DMA: W_4 of slab s+1 (other slot, read in phase 4 of slab s-1) closes that slab
+    read_a(sb); read_b(sb, C0{});
+    stage_w(slot ^ 1, C4{});
+    advance();
+    lds_wait<0>();
+    bar();
+    mma(C0{});
+    bar();
+    // ---- phase 1: W_1 ; DMA: W_0 and A rows 0-63 of slab s+2 (this slot, read in phase 0)
+    read_b(sb, C1{});
+    stage_w(slot, C0{}); stage_a(slot, C0{});
+    stats();
+    lds_wait<0>();
+    bar();
+    mma(C1{});
+    bar();
+    // ---- phase 2
+    read_b(sb, C2{});
+    stage_w(slot, C1{}); stage_a(slot, C1{});
+    lds_wait<0>();
+    bar();
+    mma(C2{});
+    bar();
+    // ---- phase 3
+    read_b(sb, C3{});
+    stage_w(slot, C2{}); stage_a(slot, C2{});
+    lds_wait<0>();
+    bar();
+    mma(C3{});
+    bar();
+    // ---- phase 4 ; everything of slab s+1 has landed once at most the 8 pieces of phases 1-4 are in flight
+    read_b(sb, C4{});
+    stage_w(slot, C3{}); stage_a(slot, C3{});
+    w3_wait_vm<8>();
+    lds_wait<0>();
+    bar();
+    mma(C4{});
+    bar();
+  }
+  if (grp == 0) bar();                                       // both groups leave the loop together
+  w3_wait_vm<0>();                                           // the zero-fill pieces staged past the last slab must not land in the strips
+  bar();
+
+  // ---- fused LayerNorm: 1/sigma of the wave's rows (lane <-> row l31 of fragment i); the two wave columns summed alternate K steps
+  float rs[FM];
+#pragma unroll
+  for (int i = 0; i < FM; ++i) rs[i] = 1.0f;
+  if constexpr (LNROWS) {
+    float* xs = (float*)(smem + 8 * 8192);                   // [wave][lane][4] partial sums behind the strips
+    *(float4*)(xs + (wid * 64 + lane) * 4) = make_float4(ln_s[0], ln_q[0], ln_s[1], ln_q[1]);
+    __syncthreads();
+    const float4 o = *(const float4*)(xs + ((wid ^ 4) * 64 + lane) * 4);      // the same rows in the other wave column
+    const float inv_k = 1.0f / (float)p.k0;
+    const float s0 = ln_s[0] + o.x, q0 = ln_q[0] + o.y, s1 = ln_s[1] + o.z, q1 = ln_q[1] + o.w;
+    const float sm0 = (s0 + __shfl_xor(s0, 32)) * inv_k, sq0 = (q0 + __shfl_xor(q0, 32)) * inv_k;
+    const float sm1 = (s1 + __shfl_xor(s1, 32)) * inv_k, sq1 = (q1 + __shfl_xor(q1, 32)) * inv_k;
+    rs[0] = rsqrtf(fmaxf(sq0 - sm0 * sm0, 0.f) + p.ln_eps);
+    rs[1] = rsqrtf(fmaxf(sq1 - sm1 * sm1, 0.f) + p.ln_eps);
+  }
+
+  // ---- epilogue (the arithmetic and its order are gemm_kernel.h's): per fragment row i and 64-column chunk, the accumulators go
+  // through the wave's strip so that 16 consecutive lanes hold 64 consecutive columns of one row
+  const __amdgpu_buffer_rsrc_t r_bias = make_rsrc(p.bias, p.bias_bytes);
+  const __amdgpu_buffer_rsrc_t r_out = make_rsrc(p.out, p.out_bytes);
+  auto strip_off = [](int row, int quad, int nq) { return row * 256 + ((quad ^ (row & (nq - 1))) << 4); };
+  char* ebuf = smem + wid * 8192;
+  const float alpha = p.blend ? p.alpha : 0.0f, one_m_alpha = 1.0f - alpha;
+  const bool blend_is_res = p.blend && p.blend == p.residual && p.ld_blend == p.ld_res;
+  auto run = [&](auto film_tag, auto res_tag, auto blend_tag) {
+    constexpr bool FILM = decltype(film_tag)::value, RES = decltype(res_tag)::value, BLEND = decltype(blend_tag)::value;
+    const __amdgpu_buffer_rsrc_t r_rv = make_rsrc(p.rowvec, FILM ? p.rowvec_bytes : 0);
+    const __amdgpu_buffer_rsrc_t r_res = make_rsrc(p.residual, RES ? p.res_bytes : 0);
+    const __amdgpu_buffer_rsrc_t r_bl = make_rsrc(p.blend, BLEND ? p.blend_bytes : 0);
+    const int rv_rows = FILM ? p.rowvec_rows : 1;
+#pragma unroll
+    for (int i = 0; i < FM; ++i) {
+      const int mb = m0 + wr * 64 + i * 32;
+      const int grp0 = mb / rv_rows, grp_split = (grp0 + 1) * rv_rows;
+#pragma unroll
+      for (int jc = 0; jc < FN; jc += 2) {
+        const int nfr = (jc + 1 < FN) ? 2 : 1;
+        const int q_per_row = nfr * 8, rows_per_pass = 64 / q_per_row;
+        const int qq = lane % q_per_row, rq = lane / q_per_row;
+        const int gn = n0 + wc * 160 + jc * 32 + qq * 4;
+        const float4 b4 = ld128f(r_bias, gn * 4);
+        float4 film_lo = make_float4(0.f, 0.f, 0.f, 0.f), film_hi = film_lo;
+        if constexpr (FILM) {
+          film_lo = ld128f(r_rv, (int)(((unsigned)grp0 * (unsigned)p.ld_rowvec + (unsigned)gn) * 4u));          // beyond the last group: out of range -> 0
+          film_hi = ld128f(r_rv, (int)(((unsigned)(grp0 + 1) * (unsigned)p.ld_rowvec + (unsigned)gn) * 4u));
+        }
+#pragma unroll
+        for (int jj = 0; jj < 2; ++jj)
+          if (jc + jj < FN) {
+#pragma unroll
+            for (int g = 0; g < 4; ++g)
+              *(float4*)(ebuf + strip_off(l31, jj * 8 + 2 * g + hi, nfr * 8)) =
+                  make_float4(acc[i][jc + jj][g * 4] * rs[i], acc[i][jc + jj][g * 4 + 1] * rs[i], acc[i][jc + jj][g * 4 + 2] * rs[i],
+                              acc[i][jc + jj][g * 4 + 3] * rs[i]);
+          }
+        // row offsets in 32-bit arithmetic, no per-row select: a row >= m lies beyond the extent its descriptor was built for
+        // ((m-1) * ld + n elements), so the bounds check returns 0 for its loads and drops its store (hipcc turns a
+        // `row < m ? offset : invalid` select around a 64-bit product into exec-masked branches with one load per side)
+        const unsigned row0 = (unsigned)(mb + rq);
+        const unsigned o_out = (row0 * (unsigned)p.ldo + (unsigned)gn) * ES, s_out = (unsigned)(rows_per_pass * p.ldo * ES);
+        const unsigned o_res = (row0 * (unsigned)p.ld_res + (unsigned)gn) * ES, s_res = (unsigned)(rows_per_pass * p.ld_res * ES);
+        const unsigned o_bl = (row0 * (unsigned)p.ld_blend + (unsigned)gn) * ES, s_bl = (unsigned)(rows_per_pass * p.ld_blend * ES);
+        constexpr int PB = 4;                                // passes per batch: loads first, stores last (in-order vmcnt)
+#pragma unroll
+        for (int pb = 0; pb < 8; pb += PB) {
+          quad_t rqv[PB], blv[PB];
+#pragma unroll
+          for (int k = 0; k < PB; ++k) {
+            const int pass = pb + k;
+            rqv[k] = blv[k] = zero_quad<Tag>();
+            if (pass * rows_per_pass < 32) {
+              if constexpr (RES) rqv[k] = ldq<Tag>(r_res, (int)(o_res + pass * s_res));
+              if constexpr (BLEND) blv[k] = ldq<Tag>(r_bl, (int)(o_bl + pass * s_bl));
+            }
+          }
+#pragma unroll
+          for (int k = 0; k < PB; ++k) {
+            const int pass = pb + k;
+            if (pass * rows_per_pass < 32) {
+              const int r = pass * rows_per_pass + rq;
+              const float4 t = *(const float4*)(ebuf + strip_off(r, qq, q_per_row));
+              const int gm = mb + r;
+              float v[4] = {(t.x + b4.x) * p.acc_scale, (t.y + b4.y) * p.acc_scale, (t.z + b4.z) * p.acc_scale, (t.w + b4.w) * p.acc_scale};
+              if constexpr (FILM) {
+                const float4 f = gm >= grp_split ? film_hi : film_lo;
+                v[0] += f.x; v[1] += f.y; v[2] += f.z; v[3] += f.w;
+              }
+              float r4[4], b4v[4];
+              quad_to_f32<Tag>(rqv[k], r4);
+              quad_to_f32<Tag>(BLEND ? blv[k] : rqv[k], b4v);
+#pragma unroll
+              for (int e = 0; e < 4; ++e) v[e] = alpha * b4v[e] + one_m_alpha * (v[e] + r4[e]);
+              stq<Tag>(r_out, (int)(o_out + pass * s_out), v);
+            }
+          }
+        }
+      }
+    }
+  };
+  const bool film = p.rowvec != nullptr, res = p.residual != nullptr, bl = p.blend && !blend_is_res;
+  using T = std::true_type; using F = std::false_type;
+  if (bl) { if (film) run(T{}, T{}, T{}); else run(F{}, T{}, T{}); }
+  else if (res) { if (film) run(T{}, T{}, F{}); else run(F{}, T{}, F{}); }
+  else { if (film) run(T{}, F{}, F{}); else run(F{}, F{}, F{}); }
+}
+
+template <typename Tag, int MODE, int LNROWS>
+static void launch_w320_inst(GemmP& p, hipStream_t st) {
+  constexpr int lds = 2 * 73728;                             // two slots (the epilogue strips and the LayerNorm partials reuse them)
+  static_assert(lds <= 160 * 1024 && 8 * 8192 + 8192 <= lds, "w320 LDS");
+  static unsigned long long attr_done = 0;
+  tt_lds_opt_in((const void*)gemm_w320_kernel<Tag, MODE, LNROWS>, lds, &attr_done);
+  hipLaunchKernelGGL((gemm_w320_kernel<Tag, MODE, LNROWS>), dim3(p.tiles_m * p.tiles_n), dim3(512), lds, st, p);
+}
+template <typename Tag>
+static void launch_w320_tag(GemmP& p, hipStream_t st) {
+  p.tiles_m = ceil_div(p.m, 256);
+  p.tiles_n = p.n / 320;
+  p.nk0 = p.k0 / 64; p.nk1 = p.k1 / 64;
+  p.kt_total = p.taps * (p.nk0 + p.nk1);
+  if (p.mode == 1) launch_w320_inst<Tag, 1, 0>(p, st);
+  else if (p.mode == 2) launch_w320_inst<Tag, 2, 0>(p, st);
+  else if (p.ln_fold) launch_w320_inst<Tag, 0, 1>(p, st);
+  else launch_w320_inst<Tag, 0, 0>(p, st);
+}
+void launch_w320_bf16(GemmP& p, hipStream_t st) { launch_w320_tag<bf16_tag>(p, st); }
+void launch_w320_f16(GemmP& p, hipStream_t st) { launch_w320_tag<f16_tag>(p, st); }
+
+}  // namespace ttg
