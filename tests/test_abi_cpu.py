@@ -101,25 +101,35 @@ def test_gemm_dispatch_rules_of_the_big_tile_kernel(lib):
 
     w320 = [256, 320, 64, 0, 4, 2, 1]
     conv = dict(mode=1, nimg=28, hin=32, win=56, hout=32, wout=56, stride=1, upsample=0)
-    assert plan(50176, 320, 1280, residual=1, ld_res=320) == (w320, 0)                   # FF2 at 32x56
-    assert plan(50176, 320, 320, residual=1, ld_res=320, blend=1, ld_blend=320)[0] == w320
+    assert plan(50176, 320, 1280, residual=16, ld_res=320) == (w320, 0)                   # FF2 at 32x56
+    assert plan(50176, 320, 320, residual=16, ld_res=320, blend=16, ld_blend=320)[0] == w320
     assert plan(50176, 960, 320, ln_fold=1)[0] == w320                                   # LayerNorm-folded QKV: 588 tiles, 77 %
     assert plan(50176, 320, 320, k1=320, lda1=320, **conv)[0] == w320                    # conv over a skip concat
     assert plan(50176, 320, 320, mode=2, frames=14, hw=1792)[0] == w320
     assert plan(200704, 320, 320)[0] == w320                                             # 64x112 latents: 784 tiles
-    assert plan(50176, 320, 320, rowvec=1, rowvec_rows=1792, ld_rowvec=320)[0] == w320
-    assert plan(50176, 320, 320, rowvec=1, rowvec_rows=16, ld_rowvec=320)[0] != w320     # row-vector groups shorter than a fragment row
-    assert plan(25088, 320, 320)[0] != w320                                              # 98 tiles
+    assert plan(50176, 320, 320, rowvec=16, rowvec_rows=1792, ld_rowvec=320)[0] == w320
+    assert plan(50176, 320, 320, rowvec=16, rowvec_rows=16, ld_rowvec=320)[0] != w320     # row-vector groups shorter than a fragment row
+    w320h = [128, 320, 64, 0, 2, 2, 1]
+    l1conv = dict(k1=640, lda1=640, mode=1, nimg=28, hin=16, win=28, hout=16, wout=28, stride=1)
+    assert plan(12544, 640, 640, **l1conv)[0] == w320h                                   # conv3x3 of the second level: 98 x 2 tiles of 128 rows
+    assert plan(25088, 320, 320)[0] != w320h and plan(12544, 640, 2560, residual=16, ld_res=640)[0] != w320h   # linears: not by default
+    assert plan(12544, 320, 320)[0][:2] not in ([256, 320], [128, 320])                  # 98 tiles of 128 rows
+    assert plan(3136, 1280, 1280)[0][:2] not in ([256, 320], [128, 320])
     assert plan(50176, 640, 320, geglu=1)[0] != w320
     assert plan(50176, 320, 320, dtype=ops.TT_F32)[0] != w320
     assert plan(50176, 320, 72)[0] != w320                                               # K % 64
     assert plan(50176, 320, 320, **dict(conv, stride=2, hin=64, win=112))[0] != w320
     assert plan(50176, 320, 320, **dict(conv, upsample=1, hin=16, win=28))[0] != w320
     assert plan(50176, 320, 320, out_f32=1)[0] != w320
+    assert plan(50176, 320, 320, residual=4, ld_res=320)[0] != w320                      # 16-bit epilogue operands must be 8-byte aligned
     assert plan(50176, 2560, 320, ln_fold=1, geglu=1)[0][:4] == [256, 256, 64, 0]        # the GEGLU projections stay on gemm_pp
     try:
         assert lib.tt_gemm_set_big_tile(0) == 0
-        assert plan(50176, 320, 1280)[0] != w320
+        assert plan(50176, 320, 1280)[0] != w320 and plan(12544, 640, 640, **l1conv)[0] != w320h
+        assert lib.tt_gemm_set_big_tile(2) == 0                                          # the 256-row kernel only
+        assert plan(50176, 320, 1280)[0] == w320 and plan(12544, 640, 640, **l1conv)[0] != w320h
+        assert lib.tt_gemm_set_big_tile(3) == 0                                          # the variant for every mode
+        assert plan(25088, 320, 320)[0] == w320h and plan(12544, 640, 2560, residual=16, ld_res=640)[0] == w320h
     finally:
         lib.tt_gemm_set_big_tile(1)
-    assert plan(50176, 320, 1280)[0] == w320
+    assert plan(50176, 320, 1280)[0] == w320 and plan(12544, 640, 640, **l1conv)[0] == w320h and plan(25088, 320, 320)[0] != w320h

@@ -28,6 +28,8 @@ void launch_pp_bf16(GemmP& p, hipStream_t st);         // gemm_pp.hip: persisten
 void launch_pp_f16(GemmP& p, hipStream_t st);
 void launch_w320_bf16(GemmP& p, hipStream_t st);       // gemm_w320.hip: 256 x 320 x 64 tiles for N = 320 t at the finest UNet level
 void launch_w320_f16(GemmP& p, hipStream_t st);
+void launch_w320h_bf16(GemmP& p, hipStream_t st);      // ... its 128-row variant (two K halves per slab) for problems with fewer rows
+void launch_w320h_f16(GemmP& p, hipStream_t st);
 }
 using namespace ttg;
 
@@ -174,21 +176,32 @@ bool pp_ok(const TtGemmArgs* a) {
 // rows) / residual / AlphaBlender epilogues.  TT_GEMM_W320=0 keeps them on the tiled kernels (A/B).
 static int g_w320 = -1;
 extern "C" int tt_gemm_set_big_tile(int32_t on) {
-  g_w320 = on ? 1 : 0;
+  g_w320 = on == 0 ? 0 : (on == 2 ? 1 : (on == 3 ? 3 : 7));  // internal: bit 0 the 256 x 320 kernel, bit 1 its 128 x 320 variant, bit 2: that one for conv3x3 only
   return TT_OK;
 }
-bool w320_ok(const TtGemmArgs* a) {
-  if (g_w320 < 0) { const char* e = getenv("TT_GEMM_W320"); g_w320 = e ? atoi(e) : 1; }
+// 0: not served; 1: 256 x 320 tiles (gemm_w320_kernel); 2: 128 x 320 tiles (gemm_w320h_kernel: problems whose 256-row tiles would fill
+// less than 70 % of a round, e.g. the second UNet level at 32x56 latents -- 12544 rows, N = 640: 98 x 2 = 196 tiles of 128 rows).
+// By default the variant takes conv3x3 problems only: A/B in the step 31.06 (256-row kernel only) / 31.01 (variant for all modes) /
+// 30.84 ms (variant for the convs); in isolation +9..16 % on the convs, +-0 on the linears and temporal convs (tools/w320_bench.py).
+int w320_route(const TtGemmArgs* a) {
+  if (g_w320 < 0) { const char* e = getenv("TT_GEMM_W320"); tt_gemm_set_big_tile(e ? atoi(e) : 1); }
   if (!g_w320 || forced_cfg() >= 0 || a->dtype == TT_F32 || a->n % 320 || (a->k0 & 63) || (a->k1 & 63) || (a->mode == 1 ? 9 : a->mode == 2 ? 3 : 1) * (a->k0 + a->k1) < 128 || a->geglu ||
       a->out_fp8 || a->out_f32 || a->out_col_hw || a->ln_fold > 1 || (a->ln_fold && (a->mode != 0 || a->k1)))
-    return false;
-  if (a->mode == 1 && (a->stride != 1 || a->upsample || a->hin != a->hout || a->win != a->wout || a->win >= 32768 || a->hin >= 32768)) return false;
-  if (a->rowvec && a->rowvec_rows < 32) return false;
-  if ((a->ldo & 3) || (a->residual && (a->ld_res & 3)) || (a->blend && (a->ld_blend & 3))) return false;
-  const long tiles = (long)ceil_div(a->m, 256) * (a->n / 320);
-  const long rounds = (tiles + 255) / 256;
-  return tiles >= 160 && tiles * 100 >= rounds * 256 * 70;       // >= 70 % of the CU x round slots busy (196 / 392 / 588 / 784 tiles: 77 %)
+    return 0;
+  if (a->mode == 1 && (a->stride != 1 || a->upsample || a->hin != a->hout || a->win != a->wout || a->win >= 32768 || a->hin >= 32768)) return 0;
+  if (a->rowvec && a->rowvec_rows < 32) return 0;
+  // 8-byte (16-bit operands) / 16-byte (fp32 vectors) epilogue accesses
+  if ((a->ldo & 3) || (a->residual && (a->ld_res & 3)) || (a->blend && (a->ld_blend & 3)) || (a->rowvec && (a->ld_rowvec & 3))) return 0;
+  if ((((size_t)a->out | (size_t)a->residual | (size_t)a->blend) & 7) || (((size_t)a->rowvec | (size_t)a->bias) & 15)) return 0;
+  for (int half = 0; half < 2; ++half) {
+    if (half && (!(g_w320 & 2) || ((g_w320 & 4) && a->mode != 1))) break;     // tt_gemm_set_big_tile(2): the 256-row kernel only
+    const long tiles = (long)ceil_div(a->m, half ? 128 : 256) * (a->n / 320);
+    const long rounds = (tiles + 255) / 256;
+    if (tiles * 100 >= rounds * 256 * 70) return 1 + half;   // >= 70 % of the CU x round slots busy (196 / 392 / 588 / 784 tiles: 77 %)
+  }
+  return 0;
 }
+bool w320_ok(const TtGemmArgs* a) { return w320_route(a) != 0; }
 // rows the persistent kernel takes when the problem is launched in two parts (0: one launch)
 static int pp_split_rows(const TtGemmArgs* a) {
   if ((a->m & 255) == 0 || a->m < 512 || pp_ok(a)) return 0;
@@ -227,8 +240,8 @@ extern "C" int tt_gemm_plan(const TtGemmArgs* a, int32_t cfg[7]) {
     cfg[0] = 256; cfg[1] = 256; cfg[2] = 64; cfg[3] = 0; cfg[4] = 2; cfg[5] = 4; cfg[6] = 1;
     return TT_OK;
   }
-  if (w320_ok(a)) {                               // gemm_w320_kernel<dtype, mode, ln>: 256 x 320 tiles, 4 x 2 waves, stages = 0
-    cfg[0] = 256; cfg[1] = 320; cfg[2] = 64; cfg[3] = 0; cfg[4] = 4; cfg[5] = 2; cfg[6] = 1;
+  if (const int route = w320_route(a)) {          // gemm_w320_kernel / gemm_w320h_kernel<dtype, mode, ln>: 256 (128) x 320 tiles, 4 x 2 (2 x 2) waves, stages = 0
+    cfg[0] = route == 1 ? 256 : 128; cfg[1] = 320; cfg[2] = 64; cfg[3] = 0; cfg[4] = route == 1 ? 4 : 2; cfg[5] = 2; cfg[6] = 1;
     return TT_OK;
   }
   if (sq320_ok(a)) {          // the streaming kernel for the 320 x 320 linears: 32-row tiles, ring depth 3 (5 without residual)
@@ -324,9 +337,10 @@ extern "C" int tt_gemm(const TtGemmArgs* a, tt_stream_t stream) {
     TT_CHECK_LAUNCH("tt_gemm");
     return TT_OK;
   }
-  if (w320_ok(a)) {
+  if (const int route = w320_route(a)) {
     p.splitk = 1; p.ws = nullptr; p.ws_bytes = 0; p.group_m_override = 0; p.group_m = 1;
-    if (a->dtype == TT_BF16) launch_w320_bf16(p, st); else launch_w320_f16(p, st);
+    if (route == 1) { if (a->dtype == TT_BF16) launch_w320_bf16(p, st); else launch_w320_f16(p, st); }
+    else { if (a->dtype == TT_BF16) launch_w320h_bf16(p, st); else launch_w320h_f16(p, st); }
     TT_CHECK_LAUNCH("tt_gemm");
     return TT_OK;
   }

@@ -142,7 +142,7 @@ def gemm(a0: torch.Tensor, w: torch.Tensor, *, a1: Optional[torch.Tensor] = None
         taps = 9 if mode == 1 else (3 if mode == 2 else 1)
         tag = _TAG[g.dtype]
         if cfg[3] == 0 and cfg[1] == 320:            # the 256 x 320 big-tile kernel (gemm_w320.hip)
-            kname = f"gemm_w320_kernel<{tag}, {mode}, {int(bool(ln_fold))}>"
+            kname = f"gemm_w320{'h' if cfg[0] == 128 else ''}_kernel<{tag}, {mode}, {int(bool(ln_fold))}>"
         elif cfg[3] == 0:                            # the persistent ping-pong kernel (gemm_pp.hip)
             kname = f"gemm_pp_kernel<{tag}, {int(bool(ln_fold))}, {int(bool(geglu))}>"
         elif cfg[0] == 32 and cfg[1] == 320:        # the opt-in streaming kernel for the 320 x 320 linears

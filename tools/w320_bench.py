@@ -59,6 +59,27 @@ def main():
     cases.append((f"tconv M={m} 320->320 +blend", 2.0 * m * 320 * 960, (x, wt),
                   dict(mode=2, tconv=(14, h * w), bias=torch.randn(320, device=dev), residual=res, blend=res, alpha=0.3,
                        out=torch.empty(m, 320, device=dev, dtype=dt))))
+    # the next level (half the height and width, C = 640): 128-row tiles at 32x56 latents; and the live rows of the finest level
+    h2, w2 = h // 2, w // 2
+    m2 = nimg * h2 * w2
+    for mm, n, k, res, ln in ((m2, 640, 2560, True, 0), (m2, 640, 640, True, 0), (m2, 1920, 640, False, 1), (m // 2, 320, 320, True, 0), (m // 2, 320, 320, False, 1)):
+        a, wt, x = r(mm, k), r(n, k) * k ** -0.5, r(mm, n)
+        kw = dict(bias=torch.randn(n, device=dev), ln_fold=ln, ln_eps=1e-5)
+        if res:
+            kw["residual"] = x
+        cases.append((f"linear {mm}x{n}x{k}{' +res' if res else ''}{' LN' if ln else ''}", 2.0 * mm * n * k, (a, wt),
+                      dict(kw, out=torch.empty(mm, n, device=dev, dtype=dt))))
+    for cin0, cin1, cout in ((640, 0, 640), (640, 640, 640), (1280, 640, 640)):
+        x0, x1 = r(m2, cin0), (r(m2, cin1) if cin1 else None)
+        cin = cin0 + cin1
+        wt = r(cout, 9 * cin) * (9 * cin) ** -0.5
+        cases.append((f"conv3x3 M={m2} cin={cin0}+{cin1} cout={cout} +film", 2.0 * m2 * cout * 9 * cin, (x0, wt),
+                      dict(a1=x1, mode=1, conv=(nimg, h2, w2, h2, w2, 1, 0), bias=torch.randn(cout, device=dev), rowvec=torch.randn(2, cout, device=dev),
+                           rowvec_rows=14 * h2 * w2, out=torch.empty(m2, cout, device=dev, dtype=dt))))
+    x, wt, res = r(m2, 640), r(640, 1920) * 1920 ** -0.5, r(m2, 640)
+    cases.append((f"tconv M={m2} 640->640 +blend", 2.0 * m2 * 640 * 1920, (x, wt),
+                  dict(mode=2, tconv=(14, h2 * w2), bias=torch.randn(640, device=dev), residual=res, blend=res, alpha=0.3,
+                       out=torch.empty(m2, 640, device=dev, dtype=dt))))
     print(f"{'problem':58s} {'tiled us':>9s} {'TF/s':>6s} | {'w320 us':>8s} {'TF/s':>6s} | speed-up")
     for name, flops, a, kw in cases:
         t = {}
