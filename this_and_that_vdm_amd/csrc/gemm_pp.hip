@@ -295,11 +295,23 @@ __global__ __launch_bounds__(512, 2) void gemm_pp_kernel(const GemmP p) {
 #pragma unroll
           for (int tt = 0; tt < 2; ++tt) {
             const float4 bv = b4[j][2 * tt], bg = b4[j][2 * tt + 1];
-            const float bvv[4] = {bv.x, bv.y, bv.z, bv.w}, bgv[4] = {bg.x, bg.y, bg.z, bg.w};
             float v[4];
+#ifdef TT_GELU_SCALAR
+            const float bvv[4] = {bv.x, bv.y, bv.z, bv.w}, bgv[4] = {bg.x, bg.y, bg.z, bg.w};
 #pragma unroll
             for (int e = 0; e < 4; ++e)
               v[e] = fmaf(acc[i][j][(2 * tt) * 4 + e], rs[i], bvv[e]) * gelu_erf_f(fmaf(acc[i][j][(2 * tt + 1) * 4 + e], rs[i], bgv[e]));
+#else
+            // two outputs per instruction (packed fp32): the GEGLU epilogue is VALU-bound (64 outputs per lane and tile)
+            {
+              const f32pk_t r2 = {rs[i], rs[i]};
+              const f32pk_t g01 = (f32pk_t){acc[i][j][(2 * tt + 1) * 4], acc[i][j][(2 * tt + 1) * 4 + 1]} * r2 + (f32pk_t){bg.x, bg.y};
+              const f32pk_t g23 = (f32pk_t){acc[i][j][(2 * tt + 1) * 4 + 2], acc[i][j][(2 * tt + 1) * 4 + 3]} * r2 + (f32pk_t){bg.z, bg.w};
+              const f32pk_t v01 = ((f32pk_t){acc[i][j][(2 * tt) * 4], acc[i][j][(2 * tt) * 4 + 1]} * r2 + (f32pk_t){bv.x, bv.y}) * gelu_erf_pk(g01);
+              const f32pk_t v23 = ((f32pk_t){acc[i][j][(2 * tt) * 4 + 2], acc[i][j][(2 * tt) * 4 + 3]} * r2 + (f32pk_t){bv.z, bv.w}) * gelu_erf_pk(g23);
+              v[0] = v01.x; v[1] = v01.y; v[2] = v23.x; v[3] = v23.y;
+            }
+#endif
             const int col = j * 16 + tt * 8 + 4 * hi;                      // output column inside the wave's 32
             lds_write8_raw(strip + l31 * 64 + (((col >> 3) ^ ((l31 >> 1) & 3)) << 4) + ((col & 7) << 1), pack2<Tag>(v[0], v[1]), pack2<Tag>(v[2], v[3]));
           }

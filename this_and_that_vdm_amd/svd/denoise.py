@@ -7,7 +7,9 @@ Per step, on device:   prep (CFG duplicate, x/sqrt(sigma^2+1), channel concat, N
   ->  UNet decoder  ->  per-frame CFG + v-prediction Euler update of the fp32 latents (in place).
 Hoisted out of the loop (step-invariant; the reference recomputes them every step):
 context K/V of all 46 cross-attention layers, frame-position embeddings, and the gesture-map latents (the
-pipeline VAE-encodes them once instead of 25 times, reference :652).
+pipeline VAE-encodes them once instead of 25 times, reference :652).  The time embedding + FiLM rows of all ResBlocks depend
+on the schedule only: begin() evaluates them for all steps at once (DenoiserBase.film_table, round 4) and step i copies its
+row block into the static buffer the captured epilogues read (TT_FILM_TABLE=0: per step inside the graph, as before).
 Step-dependent scalars (sigma_i, sigma_{i+1}, t_i) live in a 3-float device buffer that is refreshed by one
 tiny copy before each replay, so a single captured graph serves all steps.  No host sync inside the loop.
 Control-guidance windows (reference :611-617,639-645): a step whose ``controlnet_keep`` is 0 multiplies every residual
@@ -18,8 +20,12 @@ from typing import Optional, Sequence
 
 import torch
 
+import os
+
 from .. import ops
 from .layers import Geom
+
+FILM_TABLE = os.environ.get("TT_FILM_TABLE", "1") != "0"
 
 
 class DenoiseLoop:
@@ -79,6 +85,10 @@ class DenoiseLoop:
         self.table = self._static_set("table", torch.stack([sig[:-1], sig[1:], f32(timesteps)], 1))       # [steps, 3]
         self.cur = self._static_set("cur", torch.zeros(3, dtype=torch.float32, device=dev))           # sigma, sigma_next, t
         self.num_steps = self.table.shape[0]
+        self.film_tab_u = self.film_tab_c = self.film_cur_u = self.film_cur_c = None
+        if FILM_TABLE:
+            self.film_tab_u = self._static_set("film_tab_u", self.unet.film_table(self.table[:, 2], self.added_time_ids, b))
+            self.film_cur_u = self._static_set("film_cur_u", self.film_tab_u[0])
         ehs = encoder_hidden_states.to(dev)
         k, vt, s, sp, zmask = self.unet.project_context(ehs)
         if self._static.setdefault("zero_ctx_mask", zmask) != zmask:
@@ -95,6 +105,9 @@ class DenoiseLoop:
             if self.controlnet._run_dtype() != self.dtype:
                 raise RuntimeError("UNet and ControlNet must run in the same 16-bit dtype inside the fused loop")
             self.cond = self._static_set("cond", f32(controlnet_cond).reshape(f, 4, h, w))
+            if FILM_TABLE:
+                self.film_tab_c = self._static_set("film_tab_c", self.controlnet.film_table(self.table[:, 2], self.added_time_ids, b))
+                self.film_cur_c = self._static_set("film_cur_c", self.film_tab_c[0])
             k, vt, s, sp, zmask_cn = self.controlnet.project_context(ehs)
             if self._static.setdefault("zero_ctx_mask_cn", zmask_cn) != zmask_cn:
                 self._graph = self._graph_off = None
@@ -133,10 +146,16 @@ class DenoiseLoop:
                                      cpad, self.dtype)
         t = self.cur[2:3]
         x_unet = x_tok if cpad == self.unet._cin_pad else x_tok[:, :self.unet._cin_pad]
-        ctx_u = self.unet._step_context(self.unet._embed(t, self.added_time_ids, g.batch, x_tok.device), self.ctx_unet)
+        if self.film_cur_u is not None:         # this step's rows of the per-request FiLM table (copied in by step())
+            ctx_u = self.unet._step_context(None, self.ctx_unet, film=self.film_cur_u)
+        else:
+            ctx_u = self.unet._step_context(self.unet._embed(t, self.added_time_ids, g.batch, x_tok.device), self.ctx_unet)
         ctx_c = None
         if cn is not None:
-            ctx_c = cn._step_context(cn._embed(t, self.added_time_ids, g.batch, x_tok.device), self.ctx_cn)
+            if self.film_cur_c is not None:
+                ctx_c = cn._step_context(None, self.ctx_cn, film=self.film_cur_c)
+            else:
+                ctx_c = cn._step_context(cn._embed(t, self.added_time_ids, g.batch, x_tok.device), self.ctx_cn)
         eps = torch.empty((g.m, self.unet.conv_out.out_channels), dtype=torch.float32, device=x_tok.device)
         halves = [Geom(1, g.frames, g.h, g.w, b, g.batch) for b in range(g.batch)] if self.split_cfg and g.batch > 1 else [g]
         rows = halves[0].m
@@ -186,6 +205,10 @@ class DenoiseLoop:
             raise RuntimeError("denoise loop already finished; call begin() for a new request")
         self.cur.copy_(self.table[self.step_index])
         use_cn = self.controlnet is not None and self.keep[self.step_index] != 0.0
+        if self.film_cur_u is not None:
+            self.film_cur_u.copy_(self.film_tab_u[self.step_index])
+            if use_cn:
+                self.film_cur_c.copy_(self.film_tab_c[self.step_index])
         if not self.use_graph:
             self._launch_step(use_cn)
         elif use_cn or self.controlnet is None:

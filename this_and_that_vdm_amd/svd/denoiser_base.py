@@ -95,6 +95,31 @@ class DenoiserBase(ModelMixin):
         hid = ops.small_linear(te, ae.w1, ae.b1, act_out=True)
         return ops.small_linear(hid, ae.w2, ae.b2, out=emb, accumulate=True)     # emb + aug_emb, fp32 [B, 1280]
 
+    def film_table(self, timesteps: torch.Tensor, added_time_ids: torch.Tensor, batch: int) -> torch.Tensor:
+        """FiLM rows of every ResBlock for EVERY step of a request: fp32 [steps, batch, sum C].  The time embedding and the
+        ResBlocks' time_emb_proj depend on the schedule only (timestep t_i and the request's added_time_ids), not on the
+        latents, so the fused loop evaluates them once per request for all steps -- `steps * batch` rows through the same
+        kernels, <= 32 rows per launch -- instead of re-reading the ~100 MB of FiLM weights in ~20 launch-bound kernels at
+        the head of every step (reference: unet_spatio_temporal_condition.py:399-432 + ResnetBlock2D.time_emb_proj, per
+        forward).  Row r of a launch is computed exactly as a single-row launch would: the values are the per-step ones bit for bit."""
+        self.prepare()
+        dev = self._film_w.device
+        t = timesteps.to(device=dev, dtype=torch.float32).reshape(-1)
+        ids = added_time_ids.to(device=dev, dtype=torch.float32).reshape(batch, -1)
+        steps = t.numel()
+        out = torch.empty((steps, batch, self._film_w.shape[0]), dtype=torch.float32, device=dev)
+        per = max(1, 32 // batch)                           # steps per launch
+        for s0 in range(0, steps, per):
+            s1 = min(steps, s0 + per)
+            rows = (s1 - s0) * batch
+            emb = self.time_embedding(self.time_proj(t[s0:s1].repeat_interleave(batch).contiguous()))
+            te = self.add_time_proj(ids.repeat(s1 - s0, 1).reshape(-1).contiguous()).reshape(rows, -1)
+            ae = self.add_embedding
+            hid = ops.small_linear(te, ae.w1, ae.b1, act_out=True)
+            ops.small_linear(hid, ae.w2, ae.b2, out=emb, accumulate=True)
+            ops.small_linear(emb, self._film_w, self._film_b, act_in=True, out=out[s0:s1].view(rows, -1))
+        return out
+
     def project_context(self, encoder_hidden_states: torch.Tensor):
         """K / V^T of every cross-attention layer from the request's context: two GEMMs, step-invariant.
         Returns an opaque tuple accepted by forward(..., _context=...)."""
@@ -119,8 +144,10 @@ class DenoiserBase(ModelMixin):
             zero_mask = sum(1 << i for i, z in enumerate(flags) if z)
         return (k_all, vt_all, s, sp, zero_mask)
 
-    def _step_context(self, emb: torch.Tensor, context) -> StepContext:
-        film = ops.small_linear(emb, self._film_w, self._film_b, act_in=True)     # every ResBlock's FiLM row at once
+    def _step_context(self, emb: Optional[torch.Tensor], context, film: Optional[torch.Tensor] = None) -> StepContext:
+        """``film``: this step's FiLM rows when the caller holds them already (DenoiseLoop: one row block of film_table)."""
+        if film is None:
+            film = ops.small_linear(emb, self._film_w, self._film_b, act_in=True)     # every ResBlock's FiLM row at once
         k_all, vt_all, s, sp, zero_mask = context
         return StepContext(film, k_all, vt_all, s, sp, attn_fp8=bool(self.attention_fp8), zero_mask=zero_mask)
 
