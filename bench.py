@@ -108,6 +108,8 @@ def kernel_profile(loop, args):
     stream -> per kernel-instance (launch count, algorithmic flops, time)."""
     from this_and_that_vdm_amd import ops
     loop.begin(**args)
+    from this_and_that_vdm_amd.svd import layers as _layers
+    side_was, _layers._Side.ENABLED = _layers._Side.ENABLED, False
     loop.use_graph = False
     loop.overlap_branches = False                   # one stream: each kernel is timed alone on the chip
     loop.step()                                     # eager warm-up
@@ -118,6 +120,7 @@ def kernel_profile(loop, args):
     rec, ops.PROFILE = ops.PROFILE, None
     loop.use_graph = True
     loop.overlap_branches = True
+    _layers._Side.ENABLED = side_was
     agg = {}
     for name, flops, e0, e1, _shape in rec:
         a = agg.setdefault(name, [0, 0.0, 0.0])

@@ -66,6 +66,25 @@ __device__ __forceinline__ void w3_epilogue_rows(const GemmP& p, const f32x16_t 
   const float rs = rss[i];
   const int mb = mb0 + i * 32;
   const int grp0 = mb / rv_rows, grp_split = (grp0 + 1) * rv_rows;       // row group of the fragment's first row, first row of the next
+  // Residual only (the common case: to_out, FF2, proj_out, conv2 + shortcut): ALL 24 loads of the fragment row are issued before
+  // the first chunk is processed.  Batch by batch (loads, wait, stores, next loads behind those stores: in-order vmcnt) a wave pays
+  // one memory round trip per batch -- 12 per tile, the whole epilogue of a K = 320 problem; up front it pays one (two) per fragment row.
+  constexpr bool PRELOAD = RES && !BLEND;
+  constexpr int NPRE = NI == 2 ? 2 : 3;                      // chunks loaded up front: what the registers next to the live accumulators hold without spilling
+  quad_t pre[PRELOAD ? NPRE : 1][PRELOAD ? 8 : 1];
+  if constexpr (PRELOAD) {
+#pragma unroll
+    for (int c = 0; c < NPRE; ++c) {
+      const int nfr = c < 2 ? 2 : 1, q_per_row = nfr * 8, rows_per_pass = 64 / q_per_row;
+      const unsigned o = ((unsigned)(mb + lane / q_per_row) * (unsigned)p.ld_res + (unsigned)(ncol0 + c * 64 + (lane % q_per_row) * 4)) * ES;
+      const unsigned st = (unsigned)(rows_per_pass * p.ld_res * ES);
+#pragma unroll
+      for (int pass = 0; pass < 8; ++pass) {
+        pre[c][pass] = zero_quad<Tag>();
+        if (pass * rows_per_pass < 32) pre[c][pass] = ldq<Tag>(r_res, (int)(o + pass * st));
+      }
+    }
+  }
 #pragma unroll
   for (int jc = 0; jc < 5; jc += 2) {
     const int nfr = (jc + 1 < 5) ? 2 : 1;
@@ -115,7 +134,8 @@ __device__ __forceinline__ void w3_epilogue_rows(const GemmP& p, const f32x16_t 
         const int pass = pb + k;
         rqv[k] = blv[k] = zero_quad<Tag>();
         if (pass * rows_per_pass < 32) {
-          if constexpr (RES) rqv[k] = ldq<Tag>(r_res, (int)(o_res + pass * s_res));
+          if (PRELOAD && jc / 2 < NPRE) rqv[k] = pre[jc / 2 < NPRE ? jc / 2 : 0][pass];
+          else if constexpr (RES) rqv[k] = ldq<Tag>(r_res, (int)(o_res + pass * s_res));
           if constexpr (BLEND) blv[k] = ldq<Tag>(r_bl, (int)(o_bl + pass * s_bl));
         }
       }

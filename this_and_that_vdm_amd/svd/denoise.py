@@ -141,6 +141,8 @@ class DenoiseLoop:
         With ``split_cfg`` the uncond / cond halves (which never interact inside the networks) become branches too."""
         g = self.geom
         cn = self.controlnet if use_cn else None
+        from . import layers as _layers
+        _layers._Side.origin = torch.cuda.current_stream().cuda_stream     # the only stream that may fork side launches under capture
         cpad = cn._cin_pad if cn is not None else self.unet._cin_pad
         x_tok = ops.prep_model_input(self.latents, self.image_latents, self.cond if use_cn else None, self.cur, 0, g.batch, g.frames, g.h, g.w,
                                      cpad, self.dtype)

@@ -107,6 +107,74 @@ class StepContext:
         return buf
 
 
+class _Side:
+    """Run launches that are independent of the caller's next launches on a second stream of the same branch (fork / join with
+    events: parallel branches of the captured hipGraph).  Used where two under-filled GEMMs of a transformer block have no
+    dependency on each other: the swapped V^T projection next to the Q|K projection (both read the block input), and the
+    output projection of the zero-context residue class next to the live class's query projection -> attention -> output
+    projection chain.  Buffers the side launch writes are allocated by the CALLER on its own stream before the fork (the caching
+    allocator's per-stream pools never see the side stream), and the caller joins before it reads them or drops them.
+    OFF by default: measured in the step (one gpurun call, interleaved) 30.99 / 30.94 ms without against 31.10 / 31.08 ms with
+    -- the forked launches compete with the neighbours they were meant to fill in; TT_SIDE_STREAM=1 enables it (A/B)."""
+    ENABLED = os.environ.get("TT_SIDE_STREAM", "0") == "1"
+    _streams: Dict[int, "torch.cuda.Stream"] = {}
+    _spare: List["torch.cuda.Stream"] = []
+    origin: Optional[int] = None        # raw handle of the stream a capture started on (set by DenoiseLoop._launch_step)
+    # events stay alive until long after the capture that recorded them has ended (destroying an event while the stream
+    # capture that recorded it is still open crashed hipStreamEndCapture); a bounded ring, refilled by later launches
+    _events: List["torch.cuda.Event"] = []
+
+    @staticmethod
+    def _event():
+        ev = torch.cuda.Event()
+        _Side._events.append(ev)
+        if len(_Side._events) > 8192:
+            del _Side._events[:4096]
+        return ev
+
+    def __init__(self):
+        self.main = torch.cuda.current_stream()
+        self.side = None
+        capturing = torch.cuda.is_current_stream_capturing()
+        # Under stream capture only the ORIGIN stream of the capture may fork: a fork from a stream that is itself a forked branch
+        # (GestureNet's encoder in DenoiseLoop) makes hipStreamEndCapture crash on ROCm 7.2 (tools/capture_fork_probe.py, pattern c)
+        if _Side.ENABLED and (not capturing or self.main.cuda_stream == _Side.origin):
+            key = self.main.cuda_stream
+            self.side = _Side._streams.get(key)
+            if self.side is None:
+                # no stream is created while a capture is open: a spare one made outside of it (the warm-up pass of
+                # DenoiseLoop._capture runs the same code eagerly) is handed to the capturing stream
+                if capturing:
+                    if not _Side._spare:
+                        return
+                    self.side = _Side._spare.pop()
+                else:
+                    self.side = torch.cuda.Stream()
+                    while len(_Side._spare) < 4:
+                        _Side._spare.append(torch.cuda.Stream())
+                _Side._streams[key] = self.side
+            ev = _Side._event()
+            ev.record(self.main)
+            self.side.wait_event(ev)
+
+    def __enter__(self):
+        if self.side is not None:
+            self._guard = torch.cuda.stream(self.side)
+            self._guard.__enter__()
+        return self
+
+    def __exit__(self, *exc):
+        if self.side is not None:
+            self._guard.__exit__(*exc)
+        return False
+
+    def join(self):
+        if self.side is not None:
+            ev = _Side._event()
+            ev.record(self.side)
+            self.main.wait_event(ev)
+
+
 class PackRegistry:
     """Collects, at pack time, the weights that are batched across layers (FiLM projections, context K/V)."""
 
@@ -399,11 +467,14 @@ def _self_attention(x, attn: Attention, wqk, bqk, wv, eps, g: Geom, ctx: StepCon
     projection (rows) and into the swapped V^T projection (columns); flash kernel."""
     c = attn.inner_dim
     fp8 = ctx.attn_fp8 and x.dtype != torch.float32
-    qk = ops.gemm(x, wqk, bias=bqk, ln_fold=1, ln_eps=eps, out_fp8=fp8)   # [M, 2C]  (e4m3 bytes on the fp8 path)
     pad = 16 if fp8 else 8                                                # V^T sequences start on 16-byte chunks
     hwp = (g.hw + pad - 1) // pad * pad
     vt = ctx.vt_buffer(c, g.n * hwp, x, ops.FP8 if fp8 else None)
-    ops.gemm(wv, x, out=vt, out_col_pad=(g.hw, hwp) if hwp != g.hw else None, ln_fold=2, ln_eps=eps, out_fp8=fp8)
+    side = _Side()                                                        # V^T projection next to the Q | K projection
+    with side:
+        ops.gemm(wv, x, out=vt, out_col_pad=(g.hw, hwp) if hwp != g.hw else None, ln_fold=2, ln_eps=eps, out_fp8=fp8)
+    qk = ops.gemm(x, wqk, bias=bqk, ln_fold=1, ln_eps=eps, out_fp8=fp8)   # [M, 2C]  (e4m3 bytes on the fp8 path)
+    side.join()
     x_norm = x
     out = torch.empty((g.m, c), dtype=x_norm.dtype, device=x_norm.device)
     return ops.attention(qk[:, :c], qk[:, c:], vt, out, nseq=g.n, lq=g.hw, heads=attn.heads, head_dim=attn.dim_head,
@@ -558,9 +629,16 @@ class TemporalBasicTransformerBlock(_Packable):
             # on the self-attention output projection, which therefore runs per class too (bias bo1 + bo2 for the dead ones):
             # no separate pass over half of the rows.
             cb, off, cc = g.ctx_batches, self.kv[0], self.kv[1]
-            for cls in range(cb):
+            side = _Side()              # the dead classes' projections (disjoint rows of t) next to the live classes' chains
+            with side:
+                for cls in range(cb):
+                    if cls not in live:
+                        tv = t[cls::cb]
+                        ops.gemm(a[cls::cb], self.wo1, bias=self.bo12, residual=tv, out=tv)
+            for cls in live:
                 tv = t[cls::cb]
-                ops.gemm(a[cls::cb], self.wo1, bias=self.bo1 if cls in live else self.bo12, residual=tv, out=tv)
+                ops.gemm(a[cls::cb], self.wo1, bias=self.bo1, residual=tv, out=tv)
+            a_self = a                  # (kept alive until the join: the side launches read it)
             for cls in range(cb):
                 tv = t[cls::cb]
                 if cls in live:
@@ -571,6 +649,8 @@ class TemporalBasicTransformerBlock(_Packable):
                                   heads=self.attn2.heads, head_dim=self.attn2.dim_head, mask=1, lk=ctx.s_ctx, k_seq_stride=ctx.s_pad,
                                   v_seq_stride=ctx.s_pad, frames=g.n, ctx_batches=cb, batch0=cls)
                     ops.gemm(a, self.wo2, bias=self.bo2, residual=tv, out=tv)
+            side.join()
+            del a_self
         if blend_fix is not None:
             return self.ff(t, residual=t, blend=xs, alpha=alpha, rowvec=blend_fix, rowvec_rows=g.hw)
         return self.ff(t, residual=t, blend=x_spatial, alpha=alpha)
