@@ -85,6 +85,15 @@ __global__ __launch_bounds__(512, 2) void gemm_pp_kernel(const GemmP p) {
     }
   };
   producer_tile(0);
+  // Workgroups that walk one tile fewer than the busiest ones (1960 tiles on 256 CUs: 88 of them) start up to ~3 x 5 us later, in
+  // four cohorts: all CUs run in lock step otherwise, so their epilogue store bursts (64 KiB each) and the restart of their DMA
+  // streams fall into the same microsecond of every round.  The delay comes out of the idle tile time those workgroups have at
+  // the end anyway (K >= 320: a tile takes >= 14 us).  Measured: K = 320 121.1 -> 117.4 us, K = 640 189.8 -> 186.6 us, the step
+  // 31.96 -> 31.80 ms (interleaved A/B in one call); twice the delay loses.
+  if (KS >= 5 && my_tiles > 0 && my_tiles * nwg < ntiles) {
+    const int units = (int)blockIdx.x & 3;
+    for (int u = 0; u < units; ++u) __builtin_amdgcn_s_sleep(127);
+  }
   // stage region R (compile-time) of the producer's slab into `slot`; region 2 (W-lo) is the last of a slab: advance
   auto stage = [&](int slot, auto reg_tag) {
     constexpr int R = decltype(reg_tag)::value;
