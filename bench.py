@@ -391,16 +391,16 @@ def main():
         # stamped with where it was measured; it is null (not a stale number) when the dominant kernel has no entry there.
         # It is reported only when that profile was taken on THIS binary (same hash of the kernel sources); otherwise null.
         traffic, traffic_src = None, None
-        tfile = os.path.join(REPO, "profiles", "r3_hbm_traffic.json")
+        tfile = os.path.join(REPO, "profiles", "r4_hbm_traffic.json")
         if os.path.exists(tfile):
             doc = json.load(open(tfile))
             if doc.get("_kernel_source_sha16") == csrc_hash():
                 traffic = doc.get(f"{a.mode}_{a.res}", {}).get(name.replace("ttg::", ""))
                 if traffic is not None:
-                    traffic_src = ("profiles/r3_hbm_traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of tools/pmc_step.py on the "
+                    traffic_src = ("profiles/r4_hbm_traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of tools/pmc_step.py on the "
                                    f"same kernel sources, sha16 {doc.get('_kernel_source_sha16')})")
             else:
-                traffic_src = ("null: profiles/r3_hbm_traffic.json was measured on other kernel sources "
+                traffic_src = ("null: profiles/r4_hbm_traffic.json was measured on other kernel sources "
                                f"({doc.get('_kernel_source_sha16')} != {csrc_hash()}); re-run tools/profile_round.sh")
         roofline = {"bound": "mfma", "kernel": name, "launches_per_step": cnt,
                     "achieved": fl / sec / 1e12, "peak": peak, "unit": "TFLOP/s",

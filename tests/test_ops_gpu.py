@@ -390,6 +390,33 @@ def test_groupnorm_one_launch(ops, dtype, c0, c1, h, w, silu):
 
 
 @pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("c,frames,h,w", [(1280, 14, 4, 7), (2560, 14, 4, 7), (640, 4, 8, 14), (1280, 14, 8, 14)])
+def test_groupnorm_cross_frame_one_launch(ops, dtype, c, frames, h, w):
+    """ops.groupnorm with frames_per_group > 1 (TemporalResnetBlock: statistics per video over frames x h x w): with the opt-in
+    bound GN_CROSS_MAX_ROWS = 512 a video of at most 512 rows is one "image" of the one-launch kernel (the frames of a video are contiguous rows); larger videos keep the
+    partial + finalize + apply route (last case: 14 x 112 rows).  Both against torch's group_norm on [B, C, F, h, w]."""
+    b = 2
+    nimg = b * frames
+    x = rnd(nimg, c, h, w, dtype=dtype, seed=1, scale=3.0) + 1.5
+    gamma, beta = rnd(c, dtype=torch.float32, seed=3) + 1, rnd(c, dtype=torch.float32, seed=4)
+    x5 = x.float().view(b, frames, c, h, w).permute(0, 2, 1, 3, 4)
+    ref = F.silu(F.group_norm(x5, 32, gamma, beta, eps=1e-5)).permute(0, 2, 1, 3, 4).reshape(nimg, c, h, w)
+    tok = x.permute(0, 2, 3, 1).reshape(-1, c).contiguous().cuda()
+    lib = ops._lib.load()
+    keep, ops.GN_CROSS_MAX_ROWS = ops.GN_CROSS_MAX_ROWS, 512          # the route is opt-in (measured: not faster in the step)
+    try:
+        y = ops.groupnorm(tok, None, nimg, h * w, frames, gamma.cuda(), beta.cuda(), 1e-5, True)
+    finally:
+        ops.GN_CROSS_MAX_ROWS = keep
+    close(y, ref.permute(0, 2, 3, 1).reshape(-1, c), dtype, scale=2.0)
+    sc, sh = ops.groupnorm_stats(tok, None, nimg, h * w, frames, gamma.cuda(), beta.cuda(), 1e-5)
+    y2 = ops.groupnorm_apply(tok, None, nimg, h * w, sc, sh, True)
+    close(y, y2.float().cpu(), dtype, scale=2.0)
+    one_launch = frames * h * w <= 512 and bool(lib.tt_groupnorm_small_supported(frames * h * w, c, ops._code(dtype)))
+    assert one_launch == (frames * h * w <= 512)
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
 @pytest.mark.parametrize("c", [64, 320, 1280])
 def test_layernorm_and_fused_frame_embedding(ops, dtype, c):
     rows = 37 * 6

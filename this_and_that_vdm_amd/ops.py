@@ -252,6 +252,12 @@ def groupnorm_apply(x0, x1, nimg, hw, scale, shift, silu: bool, out=None):
 
 
 GN_SMALL = os.environ.get("TT_GN_SMALL", "1") != "0"      # A/B switch for the one-launch GroupNorm
+# cross-frame statistics (TemporalResnetBlock: one GroupNorm per video over frames x h x w): the frames of a video are contiguous
+# rows, so a video is one "image" of frames * hw rows for the one-launch kernel (a launch then has batch x 16 working blocks).
+# OFF by default (0 rows): one launch instead of three (-44 launches per step at the coarsest level, 14 x 28 = 392 rows per video),
+# but the step is not faster -- 30.40 / 30.42 ms without, 30.46 / 30.47 with a bound of 512 rows, 30.62 / 30.60 with 2048 (one
+# gpurun call, interleaved): the three short launches hide behind the other branch.  TT_GN_CROSS_ROWS=512 enables it (A/B, tests).
+GN_CROSS_MAX_ROWS = int(os.environ.get("TT_GN_CROSS_ROWS", "0"))
 
 
 def groupnorm(x0, x1, nimg, hw, frames_per_group, gamma, beta, eps, silu: bool):
@@ -260,6 +266,9 @@ def groupnorm(x0, x1, nimg, hw, frames_per_group, gamma, beta, eps, silu: bool):
     lib = _lib.load()
     c0 = x0.shape[-1]
     c1 = 0 if x1 is None else x1.shape[-1]
+    if GN_SMALL and frames_per_group > 1 and nimg % frames_per_group == 0 and frames_per_group * hw <= GN_CROSS_MAX_ROWS and \
+            lib.tt_groupnorm_small_supported(frames_per_group * hw, c0 + c1, _code(x0.dtype)):
+        nimg, hw, frames_per_group = nimg // frames_per_group, frames_per_group * hw, 1
     if GN_SMALL and frames_per_group == 1 and lib.tt_groupnorm_small_supported(hw, c0 + c1, _code(x0.dtype)):
         out = torch.empty((nimg * hw, c0 + c1), dtype=x0.dtype, device=x0.device)
         check(lib.tt_groupnorm_small(_p(x0), c0, _p(x1), c1, nimg, hw, _p(gamma), _p(beta), eps, int(silu), _p(out), out.stride(0),
