@@ -38,7 +38,13 @@ __device__ __forceinline__ void lds_write8_raw(unsigned addr, unsigned a, unsign
 template <typename Tag, int LNROWS, int GEGLU>
 __global__ __launch_bounds__(512, 2) void gemm_pp_kernel(const GemmP p) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
+#ifdef TT_PP_HALF_PROBE   // probe only (never shipped): 128 x 256 tiles = the A-lo half of every quadrant schedule; measures the K-loop rate at 48 KiB of DMA per slab
+  constexpr int BM = 128, BN = 256, WTM = 64, WTN = 64, FM = 2, FN = 2, CPR = 8, ES = 2;
+  constexpr bool HALF = true;
+#else
   constexpr int BM = 256, BN = 256, WTM = 128, WTN = 64, FM = 4, FN = 2, CPR = 8, ES = 2;
+  constexpr bool HALF = false;
+#endif
   constexpr int REG = 16384, SLOT = 4 * REG, STRIP_OFF = 2 * SLOT;      // regions of a slot: 0 A-lo, 1 A-hi, 2 W-lo, 3 W-hi
   constexpr bool SPLIT = LNROWS && GEGLU;                               // LayerNorm sums split over the waves of a row (needs the free strip half)
   static_assert(Elem<Tag>::ES == 2, "16-bit storage types only");
@@ -77,9 +83,9 @@ __global__ __launch_bounds__(512, 2) void gemm_pp_kernel(const GemmP p) {
 #pragma unroll
     for (int i = 0; i < 2; ++i) {
       const int c = i * 512 + tid, rr = c >> 3, ch = (c & 7) ^ tile_swz<CPR>(rr);
-      const int ar = (rr >> 6) * 128 + (rr & 63), br = (rr >> 5) * 64 + (rr & 31);
+      const int ar = HALF ? rr : (rr >> 6) * 128 + (rr & 63), br = (rr >> 5) * 64 + (rr & 31);
       pv[0][i] = (ok && m0 + ar < p.m) ? (int)(((long)(m0 + ar) * p.lda0 + ch * 8) * ES) : kInv;
-      pv[1][i] = (ok && m0 + ar + 64 < p.m) ? (int)(((long)(m0 + ar + 64) * p.lda0 + ch * 8) * ES) : kInv;
+      pv[1][i] = (!HALF && ok && m0 + ar + 64 < p.m) ? (int)(((long)(m0 + ar + 64) * p.lda0 + ch * 8) * ES) : kInv;
       pv[2][i] = (ok && n0 + br < p.n) ? (int)(((long)(n0 + br) * p.ldw + ch * 8) * ES) : kInv;
       pv[3][i] = (ok && n0 + br + 32 < p.n) ? (int)(((long)(n0 + br + 32) * p.ldw + ch * 8) * ES) : kInv;
     }
@@ -105,7 +111,7 @@ __global__ __launch_bounds__(512, 2) void gemm_pp_kernel(const GemmP p) {
       if (R < 2) __builtin_amdgcn_raw_ptr_buffer_load_lds(ra, (__attribute__((address_space(3))) void*)(base + i * 8192), 16, v, soff, 0, 0);
       else __builtin_amdgcn_raw_ptr_buffer_load_lds(rw, (__attribute__((address_space(3))) void*)(base + i * 8192), 16, v, soff, 0, 0);
     }
-    if constexpr (R == 2) { if (++p_ks == KS) { p_ks = 0; ++p_it; producer_tile(p_it); } }
+    if constexpr (R == (HALF ? 3 : 2)) { if (++p_ks == KS) { p_ks = 0; ++p_it; producer_tile(p_it); } }
   };
   using R0 = std::integral_constant<int, 0>; using R1 = std::integral_constant<int, 1>;
   using R2 = std::integral_constant<int, 2>; using R3 = std::integral_constant<int, 3>;
@@ -198,9 +204,15 @@ __global__ __launch_bounds__(512, 2) void gemm_pp_kernel(const GemmP p) {
 
   // ---- prologue: slab 0 (slot 0) complete + A-lo, W-hi, A-hi of slab 1 (slot 1), as the steady state would have issued them
   // (W-lo closes a slab: it advances the producer cursor, so it goes last)
+  if constexpr (HALF) {
+    stage(0, R0{}); stage(0, R2{}); stage(0, R3{});
+    stage(1, R0{}); stage(1, R2{});
+    pp_wait_vm<4>();
+  } else {
   stage(0, R0{}); stage(0, R3{}); stage(0, R1{}); stage(0, R2{});
   stage(1, R0{}); stage(1, R3{}); stage(1, R1{});
   pp_wait_vm<6>();
+  }
   bar();
   if (grp == 1) bar();                                       // group 1 runs one barrier behind group 0
 
@@ -234,7 +246,7 @@ __global__ __launch_bounds__(512, 2) void gemm_pp_kernel(const GemmP p) {
       // partial sums of this wave (its K steps, its half of each K step) -> upper half of its strip, 32 bytes per lane; after the
       // barrier every wave adds the four partials of its wave row (strips wr*4 + 0..3) for its own half; the halves meet below
       lds_write16_raw(strip + 2048 + lane * 32, ln_s[0], ln_q[0], ln_s[1], ln_q[1]);
-      lds_write16_raw(strip + 2048 + lane * 32 + 16, ln_s[2], ln_q[2], ln_s[3], ln_q[3]);
+      if constexpr (FM == 4) lds_write16_raw(strip + 2048 + lane * 32 + 16, ln_s[FM - 2], ln_q[FM - 2], ln_s[FM - 1], ln_q[FM - 1]);
       lds_wait<0>();
       bar();
       raw_u32x4_t t[4][2];
@@ -243,7 +255,7 @@ __global__ __launch_bounds__(512, 2) void gemm_pp_kernel(const GemmP p) {
       for (int c = 0; c < 4; ++c) { t[c][0] = lds_read16_raw(row_strips + c * 4096); t[c][1] = lds_read16_raw(row_strips + c * 4096 + 16); }
       lds_wait<0>();
 #pragma unroll
-      for (int h = 0; h < 2; ++h) {
+      for (int h = 0; h < FM / 2; ++h) {
         ln_s[2 * h] = (__uint_as_float(t[0][h].x) + __uint_as_float(t[1][h].x)) + (__uint_as_float(t[2][h].x) + __uint_as_float(t[3][h].x));
         ln_q[2 * h] = (__uint_as_float(t[0][h].y) + __uint_as_float(t[1][h].y)) + (__uint_as_float(t[2][h].y) + __uint_as_float(t[3][h].y));
         ln_s[2 * h + 1] = (__uint_as_float(t[0][h].z) + __uint_as_float(t[1][h].z)) + (__uint_as_float(t[2][h].z) + __uint_as_float(t[3][h].z));
@@ -349,6 +361,31 @@ __global__ __launch_bounds__(512, 2) void gemm_pp_kernel(const GemmP p) {
   for (int s = 0; s < S; ++s) {
     const int slot = s & 1;
     const unsigned sb = lds_base + slot * SLOT;
+    if constexpr (HALF) {
+      // p0: A-lo + W-lo ; DMA: W-hi of slab s+1 (other slot; read in p1 of slab s-1) closes that slab
+      read_a(sb, 0); read_b(sb, 0);
+      if (c_ks == 0) {
+        const int m0 = (c_it & 1) ? q_m0[1] : q_m0[0], n0 = (c_it & 1) ? q_n0[1] : q_n0[0];
+        c_m0 = m0; c_n0 = n0;
+        const int gn = n0 + wc * 64 + lane;
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rb, (__attribute__((address_space(3))) void*)(smem + STRIP_OFF + wid * 4096), 4,
+                                                 gn < p.n ? gn * 4 : kInv, 0, 0, 0);
+      }
+      stage(slot ^ 1, R3{});
+      lds_wait<0>();
+      bar();
+      mma(I0{}, I0{});
+      bar();
+      // p1: W-hi ; DMA: A-lo and W-lo of slab s+2 (this slot, read in p0)
+      read_b(sb, 1);
+      stage(slot, R0{}); stage(slot, R2{});
+      stats(I0{});
+      pp_wait_vm<4>();
+      lds_wait<0>();
+      bar();
+      mma(I0{}, I1{});
+      bar();
+    } else {
     // ---- p0 (0,0): A-lo + W-lo ; DMA: [bias of this tile] + W-lo of slab s+1 (the other slot; released in p3 of slab s-1)
     read_a(sb, 0); read_b(sb, 0);
     if (c_ks == 0) {
@@ -390,6 +427,7 @@ __global__ __launch_bounds__(512, 2) void gemm_pp_kernel(const GemmP p) {
     bar();
     mma(I1{}, I0{});
     bar();
+    }
     if (++c_ks == KS) {
       c_ks = 0;
       if (grp == 0) bar();                                   // both groups run the epilogue together ...
@@ -404,7 +442,11 @@ static void launch_pp_inst(GemmP& p, hipStream_t st) {
   constexpr int lds = 2 * 65536 + 8 * 4096;
   static unsigned long long attr_done = 0;
   tt_lds_opt_in((const void*)gemm_pp_kernel<Tag, LNROWS, GEGLU>, lds, &attr_done);
+#ifdef TT_PP_HALF_PROBE
+  p.tiles_m = ceil_div(p.m, 128);
+#else
   p.tiles_m = ceil_div(p.m, 256);
+#endif
   p.tiles_n = ceil_div(p.n, 256);
   int gm = 1;                                               // group height of the tile order: one XCD's 32 resident tiles ~ gm x 32/gm
   if (p.tiles_n > 8) while (gm * 2 * gm * 2 <= 32 && gm * 2 <= p.tiles_m) gm *= 2;
