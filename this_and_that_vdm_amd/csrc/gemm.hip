@@ -240,12 +240,12 @@ extern "C" int tt_gemm_plan(const TtGemmArgs* a, int32_t cfg[7]) {
     cfg[0] = 256; cfg[1] = 256; cfg[2] = 64; cfg[3] = 0; cfg[4] = 2; cfg[5] = 4; cfg[6] = 1;
     return TT_OK;
   }
-  if (const int route = w320_route(a)) {          // gemm_w320_kernel / gemm_w320h_kernel<dtype, mode, ln>: 256 (128) x 320 tiles, 4 x 2 (2 x 2) waves, stages = 0
-    cfg[0] = route == 1 ? 256 : 128; cfg[1] = 320; cfg[2] = 64; cfg[3] = 0; cfg[4] = route == 1 ? 4 : 2; cfg[5] = 2; cfg[6] = 1;
-    return TT_OK;
-  }
   if (sq320_ok(a)) {          // the streaming kernel for the 320 x 320 linears: 32-row tiles, ring depth 3 (5 without residual)
     cfg[0] = SQ_ROWS; cfg[1] = SQ_N; cfg[2] = SQ_K; cfg[3] = a->residual ? 3 : 5; cfg[4] = 1; cfg[5] = SQ_WAVES; cfg[6] = 1;
+    return TT_OK;
+  }
+  if (const int route = w320_route(a)) {          // gemm_w320_kernel / gemm_w320h_kernel<dtype, mode, ln>: 256 (128) x 320 tiles, 4 x 2 (2 x 2) waves, stages = 0
+    cfg[0] = route == 1 ? 256 : 128; cfg[1] = 320; cfg[2] = 64; cfg[3] = 0; cfg[4] = route == 1 ? 4 : 2; cfg[5] = 2; cfg[6] = 1;
     return TT_OK;
   }
   Plan pl = plan_for(a);
@@ -260,7 +260,7 @@ extern "C" int tt_gemm_plan(const TtGemmArgs* a, int32_t cfg[7]) {
 extern "C" size_t tt_gemm_ws_bytes(const TtGemmArgs* a) {
   if (!a || a->m <= 0 || a->n <= 0) return 0;
   if (pp_ok(a)) return 0;
-  if (!pp_split_rows(a) && w320_ok(a)) return 0;
+  if (!pp_split_rows(a) && (sq320_ok(a) || w320_ok(a))) return 0;
   if (const int rows = pp_split_rows(a)) { TtGemmArgs head, tail; pp_split(a, rows, &head, &tail); return tt_gemm_ws_bytes(&tail); }
   const Plan pl = plan_for(a);
   return pl.splitk > 1 ? (size_t)pl.splitk * a->m * a->n * sizeof(float) : 0;
@@ -337,16 +337,16 @@ extern "C" int tt_gemm(const TtGemmArgs* a, tt_stream_t stream) {
     TT_CHECK_LAUNCH("tt_gemm");
     return TT_OK;
   }
+  if (sq320_ok(a)) {
+    p.splitk = 1; p.ws = nullptr; p.ws_bytes = 0; p.group_m_override = 0; p.group_m = 1;
+    if (a->dtype == TT_BF16) launch_sq320_bf16(p, st); else launch_sq320_f16(p, st);
+    TT_CHECK_LAUNCH("tt_gemm");
+    return TT_OK;
+  }
   if (const int route = w320_route(a)) {
     p.splitk = 1; p.ws = nullptr; p.ws_bytes = 0; p.group_m_override = 0; p.group_m = 1;
     if (route == 1) { if (a->dtype == TT_BF16) launch_w320_bf16(p, st); else launch_w320_f16(p, st); }
     else { if (a->dtype == TT_BF16) launch_w320h_bf16(p, st); else launch_w320h_f16(p, st); }
-    TT_CHECK_LAUNCH("tt_gemm");
-    return TT_OK;
-  }
-  if (sq320_ok(a)) {
-    p.splitk = 1; p.ws = nullptr; p.ws_bytes = 0; p.group_m_override = 0; p.group_m = 1;
-    if (a->dtype == TT_BF16) launch_sq320_bf16(p, st); else launch_sq320_f16(p, st);
     TT_CHECK_LAUNCH("tt_gemm");
     return TT_OK;
   }
