@@ -177,6 +177,18 @@ typedef struct TtAttnArgs {
    * operands are LayerNorm-ed projections, far inside e4m3's +-448.  Its tolerance is e4m3's (3 mantissa bits), see
    * tests/test_ops_gpu.py::test_attention_fp8. */
   int32_t fp8;
+  /* Fused query projection (ABI 6; masks 1 / 2, head_dim 64, 16-bit dtype): when qx != NULL, `q` is ignored (may be NULL) and every
+   * block computes its own queries  Q = LN(x rows) Wq^T + bq  in front of the key loop -- the nn.Linear to_q of the cross-attention
+   * (BasicTransformerBlock.attn2 / TemporalBasicTransformerBlock.attn2, reached from transformer_temporal.py:353-365) and the
+   * LayerNorm in front of it, without a Q tensor or a launch of their own.  qx [nseq*lq rows, ldqx] holds the UN-normalised hidden
+   * states (rows addressed like q: query r of sequence s is row s*lq + r), qc = the LayerNorm width = columns of wq.
+   * wq [heads*64, ldwq] and bq [heads*64] are the LayerNorm-folded projection (packing.fold_layernorm) with bits 2 and 3 of the
+   * row index swapped inside every group of 16 rows (packing.permute_q_rows): the projection's MFMA accumulators then ARE the
+   * Q^T operand fragments of the score product. */
+  const void* qx; int64_t ldqx;
+  const void* wq; int64_t ldwq;
+  const float* bq;
+  int32_t qc; float ln_eps;
 } TtAttnArgs;
 int tt_attention(const TtAttnArgs* args, tt_stream_t stream);
 

@@ -127,7 +127,8 @@ def test_zero_context_shortcut_and_general_path(dtype):
 
     def counting(q, *a, **k):
         if k.get("mask") in (1, 2):              # every cross-attention launch: spatial (mask 1) and temporal (mask 2; the
-            rows.append(q.shape[0])              # temporal shortcut runs its live residue class as a mask-1 launch)
+            # temporal shortcut runs its live residue class as a mask-1 launch); with the fused query projection q is None
+            rows.append((q if q is not None else k["qx"]).shape[0])
         return real(q, *a, **k)
 
     with torch.no_grad():

@@ -327,6 +327,51 @@ def test_attention_cross_spatial_and_temporal(ops, dtype, s):
     close(out2.view(b * f, hw, c), ref2, dtype)
 
 
+@pytest.mark.parametrize("dtype", DTYPES16)
+@pytest.mark.parametrize("c,heads,b,f,hw,s,strided", [(320, 5, 2, 3, 300, 78, False), (640, 10, 2, 2, 130, 78, False), (1280, 20, 2, 3, 40, 5, False),
+                                                     (320, 5, 1, 4, 256, 78, True), (128, 2, 2, 2, 37, 1, False)])
+def test_attention_fused_query_projection(ops, dtype, c, heads, b, f, hw, s, strided):
+    """tt_attention with the query projection fused in (TtAttnArgs.qx): Q = LN(x) Wq^T computed by the attention blocks themselves
+    from LayerNorm-folded, row-permuted weights (packing.permute_q_rows).  Against (a) the separate projection GEMM (ln_fold = 1)
+    followed by the attention kernel on the same operands and (b) torch (layer_norm -> linear -> SDPA) in fp32, for the spatial
+    (mask 1) and the temporal (mask 2, quirk Q3 pairing) cross-attention; ragged query blocks (300 = 2 x 128 + 44 rows), rows of
+    a strided view (the live residue class of the temporal block)."""
+    from this_and_that_vdm_amd.packing import fold_layernorm, permute_q_rows, zero_sum_round
+    d = 64
+    sp = (s + 7) // 8 * 8
+    rows = b * f * hw
+    big = (rnd(2 * rows if strided else rows, c, dtype=torch.float32, seed=1, scale=1.5) + rnd(2 * rows if strided else rows, 1, dtype=torch.float32, seed=9)).to(dtype).cuda()
+    x = big[1::2] if strided else big
+    wq = rnd(c, c, dtype=dtype, seed=2, scale=c ** -0.5)
+    g, be = rnd(c, dtype=torch.float32, seed=4, scale=0.2) + 1, rnd(c, dtype=torch.float32, seed=5, scale=0.3)
+    wf, bf = fold_layernorm(wq.float(), None, g, be)
+    wqf = zero_sum_round(wf, dtype)
+    kc, vc = rnd(b, s, c, dtype=dtype, seed=6), rnd(b, s, c, dtype=dtype, seed=7)
+    kpad = torch.zeros(b, sp, c, dtype=dtype)
+    kpad[:, :s] = kc
+    vt = torch.zeros(c, b * sp, dtype=dtype)
+    vt.view(c, b, sp)[:, :, :s] = vc.permute(2, 0, 1)
+    kd, vd = kpad.reshape(-1, c).cuda(), vt.cuda()
+    q_ref = F.linear(F.layer_norm(x.float().cpu(), (c,), g, be, 1e-5), wq.float())
+    wq_d, bq_d = wqf.cuda(), bf.cuda()
+    wq_p, bq_p = permute_q_rows(wq_d), permute_q_rows(bq_d)
+    assert torch.equal(permute_q_rows(wq_p), wq_d)                       # an involution
+    for mask in (1, 2):
+        kw = dict(nseq=b * f, lq=hw, heads=heads, head_dim=d, mask=mask, lk=s, k_seq_stride=sp, v_seq_stride=sp, frames=f, ctx_batches=b)
+        q = ops.gemm(x, wq_d, bias=bq_d, ln_fold=1, ln_eps=1e-5)
+        two = ops.attention(q, kd, vd, torch.empty(rows, c, dtype=dtype, device="cuda"), **kw)
+        one = ops.attention(None, kd, vd, torch.full((rows, c), float("nan"), dtype=dtype, device="cuda"), qx=x, wq=wq_p, bq=bq_p, ln_eps=1e-5, **kw)
+        tol = TOL[dtype]
+        torch.testing.assert_close(one.float(), two.float(), rtol=tol["rtol"], atol=tol["atol"])
+        if mask == 1:
+            ref = _sdpa(q_ref.view(b * f, hw, c), kc.float().repeat_interleave(f, 0), vc.float().repeat_interleave(f, 0), heads)
+        else:
+            sel = (torch.arange(b)[:, None] * hw + torch.arange(hw)[None]) % b
+            qt = q_ref.view(b, f, hw, c).permute(0, 2, 1, 3).reshape(b * hw, f, c)
+            ref = _sdpa(qt, kc.float()[sel.reshape(-1)], vc.float()[sel.reshape(-1)], heads).view(b, hw, f, c).permute(0, 2, 1, 3).reshape(b * f, hw, c)
+        torch.testing.assert_close(one.float().cpu().view(b * f, hw, c), ref, rtol=tol["rtol"] * 2, atol=tol["atol"] * 2)
+
+
 @pytest.mark.parametrize("dtype", DTYPES)
 @pytest.mark.parametrize("frames,heads,d", [(14, 3, 64), (4, 1, 64), (25, 2, 64), (3, 2, 128)])
 def test_temporal_self_attention(ops, dtype, frames, heads, d):

@@ -38,6 +38,9 @@ class TtAttnArgs(C.Structure):
         ("nseq", C.c_int32), ("lq", C.c_int32), ("heads", C.c_int32), ("head_dim", C.c_int32),
         ("mask", C.c_int32), ("lk", C.c_int32), ("k_seq_stride", C.c_int32), ("v_seq_stride", C.c_int32),
         ("frames", C.c_int32), ("ctx_batches", C.c_int32), ("dtype", C.c_int32), ("batch0", C.c_int32), ("fp8", C.c_int32),
+        # ABI 6: fused query projection of the cross-attention (qx != NULL: Q = LN(qx rows) wq^T + bq computed by the kernel)
+        ("qx", C.c_void_p), ("ldqx", C.c_int64), ("wq", C.c_void_p), ("ldwq", C.c_int64), ("bq", C.c_void_p),
+        ("qc", C.c_int32), ("ln_eps", C.c_float),
     ]
 
 
@@ -119,7 +122,7 @@ def load():
     for name, (res, args) in SIGNATURES.items():
         fn = getattr(lib, name)          # AttributeError here == ABI mismatch with include/ttvdm.h
         fn.restype, fn.argtypes = res, args
-    if lib.tt_abi_version() != 5:
+    if lib.tt_abi_version() != 6:
         raise RuntimeError("libttvdm.so ABI version mismatch")
     _lib = lib
     return lib

@@ -25,10 +25,39 @@ struct AttnP {
   long vt_cols_total;   // columns of vt that exist
   unsigned k_bytes, vt_bytes;   // extents for the buffer descriptors
   float scale_log2e;
+  // fused query projection (cross-attention, round 4): Q = LN(x) Wq^T + bq computed by the block itself (QP instances)
+  const char* qx; long ldqx; const char* wq; long ldwq; const float* bq; int qc; float ln_eps;
+  unsigned qx_bytes, wq_bytes;
 };
 
 constexpr int QB = 128;   // queries per block
 constexpr int KB = 64;    // keys per tile
+
+// sum and sum of squares of one 16-byte operand chunk (fused LayerNorm statistics of the fused query projection; the same packed
+// dot products as gemm_kernel.h's ln_stat)
+typedef __attribute__((ext_vector_type(2))) _Float16 at_half2;
+typedef __attribute__((ext_vector_type(2))) __bf16 at_bf162;
+template <typename Tag> __device__ __forceinline__ void ln_stat_attn(const raw_u32x4_t& f, float& s, float& q) {}
+template <> __device__ __forceinline__ void ln_stat_attn<bf16_tag>(const raw_u32x4_t& f, float& s, float& q) {
+  const at_bf162 one = __builtin_bit_cast(at_bf162, 0x3F803F80u);
+  const unsigned w[4] = {f.x, f.y, f.z, f.w};
+#pragma unroll
+  for (int d = 0; d < 4; ++d) {
+    const at_bf162 x = __builtin_bit_cast(at_bf162, w[d]);
+    s = __builtin_amdgcn_fdot2_f32_bf16(x, one, s, false);
+    q = __builtin_amdgcn_fdot2_f32_bf16(x, x, q, false);
+  }
+}
+template <> __device__ __forceinline__ void ln_stat_attn<f16_tag>(const raw_u32x4_t& f, float& s, float& q) {
+  const at_half2 one = __builtin_bit_cast(at_half2, 0x3C003C00u);
+  const unsigned w[4] = {f.x, f.y, f.z, f.w};
+#pragma unroll
+  for (int d = 0; d < 4; ++d) {
+    const at_half2 x = __builtin_bit_cast(at_half2, w[d]);
+    s = __builtin_amdgcn_fdot2(x, one, s, false);
+    q = __builtin_amdgcn_fdot2(x, x, q, false);
+  }
+}
 
 // raw v_exp_f32: inputs here are <= 0 or -inf (exp2(-inf) = 0), no denormal/range fix-ups needed
 __device__ __forceinline__ float fast_exp2(float x) { return __builtin_amdgcn_exp2f(x); }
@@ -51,7 +80,14 @@ __device__ __forceinline__ Bid3 xcd_remap3() {
   return o;
 }
 
-template <typename Tag, int D, int MASK>
+// QP (cross-attention, D = 64, 16-bit storage): the block computes its own queries.  Q_h[128 x 64] = LN(x rows) Wq_h^T + bq_h is a
+// 128 x 64 x C mini-GEMM in front of the key loop (x rows and the head's 64 rows of Wq staged slab by slab through a 3-deep
+// LDS ring; LayerNorm folded into Wq by the caller, 1/sigma from the operand fragments as in tt_gemm ln_fold = 1) whose
+// accumulators ARE the Q^T operand of S^T = K Q^T: lane (query l31, half hi) of fragment j holds output columns
+// 32 j + 8 g + 4 hi + e; registers g = 2t, 2t+1 of fragment j are the 8 contraction slots of key step 2j + t.  The caller
+// stores Wq / bq with bits 2 and 3 of the row index swapped inside every 16-row group (packing.permute_q_rows), so slot s of
+// half hi is head dimension 16 (2j + t) + 8 hi + s -- what the K fragment of that step holds.  No Q tensor, no separate launch.
+template <typename Tag, int D, int MASK, bool QP = false>
 __global__ __launch_bounds__(256, (D == 64 && Elem<Tag>::ES == 2) ? 2 : 1) void attn_kernel(const AttnP p) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   typedef typename Elem<Tag>::quad_t quad_t;
@@ -94,10 +130,93 @@ __global__ __launch_bounds__(256, (D == 64 && Elem<Tag>::ES == 2) ? 2 : 1) void 
   const int qrow = (qblk * QB + wid * 32 + l31) * qstride + qcls;
   const bool qok = qrow < p.lq;
   uint4 qf[DS];
-  {
+  if constexpr (!QP) {
     const char* qp = p.q + (((long)seq * p.lq + (qok ? qrow : 0)) * p.ldq + head * D) * ES;
 #pragma unroll
     for (int ds = 0; ds < DS; ++ds) qf[ds] = qok ? *(const uint4*)(qp + (ds * 2 + hi) * 16) : make_uint4(0, 0, 0, 0);
+  } else {
+    static_assert(!QP || (D == 64 && ES == 2 && MASK != 0), "fused query projection: cross-attention, head dimension 64, 16-bit storage");
+    constexpr int QSLAB = QB * 128 + 64 * 128, QNST = 3;      // 16 KiB of x rows + 8 KiB of Wq rows per 64-deep slab
+    constexpr int QINV = (int)0x80000000;
+    const __amdgpu_buffer_rsrc_t rx = __builtin_amdgcn_make_buffer_rsrc((void*)p.qx, 0, p.qx_bytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rwq = __builtin_amdgcn_make_buffer_rsrc((void*)p.wq, 0, p.wq_bytes, 0x00020000);
+    int xo[4], wo[2];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int slot = i * 256 + tid, r = slot >> 3, c = (slot & 7) ^ tile_swz<8>(r);
+      const int qr = (qblk * QB + r) * qstride + qcls;
+      xo[i] = qr < p.lq ? (int)((((long)seq * p.lq + qr) * p.ldqx + c * 8) * 2) : QINV;
+    }
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      const int slot = i * 256 + tid, r = slot >> 3, c = (slot & 7) ^ tile_swz<8>(r);
+      wo[i] = (int)((((long)head * 64 + r) * p.ldwq + c * 8) * 2);
+    }
+    const int nslab = p.qc >> 6;
+    auto qstage = [&](int s) {                     // always 6 pieces (counted waits); beyond the last slab they fetch nothing
+      char* dst = smem + (s % QNST) * QSLAB + wid * 1024;
+      const int soff = __builtin_amdgcn_readfirstlane(s * 128);
+      const bool ok = s < nslab;
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rx, (__attribute__((address_space(3))) void*)(dst + i * 4096), 16, ok ? xo[i] : QINV, soff, 0, 0);
+#pragma unroll
+      for (int i = 0; i < 2; ++i)
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rwq, (__attribute__((address_space(3))) void*)(dst + QB * 128 + i * 4096), 16, ok ? wo[i] : QINV, soff, 0, 0);
+    };
+    f32x16_t qa[2];
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) qa[j][r] = 0.f;
+    float ls = 0.f, lq2 = 0.f;
+    const unsigned qbase = lds_addr(smem);
+    const int xr = wid * 32 + l31;
+    unsigned xa[4], wa[4];
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) {
+      xa[ks] = tile_off<8>(xr, ks * 2 + hi);
+      wa[ks] = QB * 128 + tile_off<8>(l31, ks * 2 + hi);      // fragment j: + j * 32 rows = + 4096 bytes (same swizzle)
+    }
+    qstage(0); qstage(1);
+    for (int s = 0; s < nslab; ++s) {
+      asm volatile("s_waitcnt vmcnt(6)" ::: "memory");        // slab s has landed (slab s+1 may be in flight)
+      __syncthreads();                                        // ... for every wave; the slot of slab s-1 is free
+      qstage(s + 2);
+      const unsigned sb = qbase + (s % QNST) * QSLAB;
+      raw_u32x4_t xf[4], wf[2][4];
+#pragma unroll
+      for (int ks = 0; ks < 4; ++ks) {
+        xf[ks] = lds_read16_raw(sb + xa[ks]);
+        wf[0][ks] = lds_read16_raw(sb + wa[ks]);
+        wf[1][ks] = lds_read16_raw_off<4096>(sb + wa[ks]);
+      }
+      lds_wait<0>();
+#pragma unroll
+      for (int ks = 0; ks < 4; ++ks) {
+        ln_stat_attn<Tag>(xf[ks], ls, lq2);
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+          qa[j] = Cvt<Tag>::mfma32(make_uint4(wf[j][ks].x, wf[j][ks].y, wf[j][ks].z, wf[j][ks].w),
+                                   make_uint4(xf[ks].x, xf[ks].y, xf[ks].z, xf[ks].w), qa[j]);
+      }
+      __builtin_amdgcn_sched_barrier(0);
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");          // the empty pieces staged past the last slab
+    __syncthreads();                                          // the ring is handed to the K / V^T tiles
+    const float inv_c = 1.0f / (float)p.qc;
+    const float sm = (ls + __shfl_xor(ls, 32)) * inv_c, sq = (lq2 + __shfl_xor(lq2, 32)) * inv_c;
+    const float rs = rsqrtf(fmaxf(sq - sm * sm, 0.f) + p.ln_eps);
+#pragma unroll
+    for (int ds = 0; ds < DS; ++ds) {
+      const int j = ds >> 1, t = ds & 1;
+      const float4 b0 = *(const float4*)(p.bq + head * 64 + 32 * j + 8 * (2 * t) + 4 * hi);
+      const float4 b1 = *(const float4*)(p.bq + head * 64 + 32 * j + 8 * (2 * t + 1) + 4 * hi);
+      const float v[8] = {fmaf(qa[j][(2 * t) * 4], rs, b0.x), fmaf(qa[j][(2 * t) * 4 + 1], rs, b0.y), fmaf(qa[j][(2 * t) * 4 + 2], rs, b0.z),
+                          fmaf(qa[j][(2 * t) * 4 + 3], rs, b0.w), fmaf(qa[j][(2 * t + 1) * 4], rs, b1.x), fmaf(qa[j][(2 * t + 1) * 4 + 1], rs, b1.y),
+                          fmaf(qa[j][(2 * t + 1) * 4 + 2], rs, b1.z), fmaf(qa[j][(2 * t + 1) * 4 + 3], rs, b1.w)};
+      qf[ds] = qok ? pack8<Tag>(v) : make_uint4(0, 0, 0, 0);
+    }
   }
 
   // staging by buffer_load ... lds: per-lane 32-bit byte offsets computed once, the tile position is a scalar offset,
@@ -588,8 +707,21 @@ void launch_attn_m(const AttnP& p, hipStream_t st) {
   const dim3 grid(cls * ((((p.lq + cls - 1) / cls) + QB - 1) / QB), p.heads, p.nseq);
   hipLaunchKernelGGL((attn_kernel<Tag, D, MASK>), grid, dim3(256), lds, st, p);
 }
+// cross-attention with the query projection fused in (D = 64, 16-bit): LDS = the 3 x 24 KiB projection ring (the K / V^T ring reuses it)
+template <typename Tag, int MASK>
+void launch_attn_qp(const AttnP& p, hipStream_t st) {
+  constexpr size_t lds = 3 * (QB * 128 + 64 * 128);
+  static unsigned long long attr_done = 0;
+  tt_lds_opt_in((const void*)attn_kernel<Tag, 64, MASK, true>, (int)lds, &attr_done);
+  const int cls = MASK == 2 ? p.ctx_batches : 1;
+  const dim3 grid(cls * ((((p.lq + cls - 1) / cls) + QB - 1) / QB), p.heads, p.nseq);
+  hipLaunchKernelGGL((attn_kernel<Tag, 64, MASK, true>), grid, dim3(256), lds, st, p);
+}
 template <typename Tag, int D>
 void launch_attn(const AttnP& p, hipStream_t st) {
+  if constexpr (D == 64 && Elem<Tag>::ES == 2) {
+    if (p.qx) { if (p.mask == 1) launch_attn_qp<Tag, 1>(p, st); else launch_attn_qp<Tag, 2>(p, st); return; }
+  }
   if (p.mask == 0) launch_attn_m<Tag, D, 0>(p, st);
   else if (p.mask == 1) launch_attn_m<Tag, D, 1>(p, st);
   else launch_attn_m<Tag, D, 2>(p, st);
@@ -774,7 +906,13 @@ void launch_tattn(const void* qkv, long ldqkv, void* out, long ldo, int batch, i
 }  // namespace
 
 extern "C" int tt_attention(const TtAttnArgs* a, tt_stream_t stream) {
-  if (!a || !a->q || !a->k || !a->vt || !a->out) TT_FAIL(TT_EINVAL, "tt_attention: null operand");
+  if (!a || (!a->q && !a->qx) || !a->k || !a->vt || !a->out) TT_FAIL(TT_EINVAL, "tt_attention: null operand");
+  if (a->qx) {
+    if (a->mask == 0 || a->head_dim != 64 || a->dtype == TT_F32 || a->fp8)
+      TT_FAIL(TT_EUNSUPPORTED, "tt_attention: the fused query projection serves cross-attention (mask 1 / 2), head_dim 64, 16-bit storage");
+    if (!a->wq || !a->bq || a->qc < 64 || (a->qc & 63) || (a->ldqx & 7) || (a->ldwq & 7) || !(a->ln_eps > 0.f))
+      TT_FAIL(TT_EINVAL, "tt_attention: fused query projection needs wq, bq, qc %% 64 == 0, row strides %% 8 == 0, ln_eps > 0");
+  }
   if (a->head_dim != 64 && a->head_dim != 128) TT_FAIL(TT_EUNSUPPORTED, "tt_attention: head_dim %d (64 or 128)", a->head_dim);
   if (a->nseq <= 0 || a->lq <= 0 || a->heads <= 0 || a->lk <= 0) TT_FAIL(TT_EINVAL, "tt_attention: empty problem");
   if (a->mask < 0 || a->mask > 2) TT_FAIL(TT_EINVAL, "tt_attention: mask %d", a->mask);
@@ -786,7 +924,7 @@ extern "C" int tt_attention(const TtAttnArgs* a, tt_stream_t stream) {
   if (a->fp8 && (a->mask != 0 || a->dtype == TT_F32)) TT_FAIL(TT_EUNSUPPORTED, "tt_attention: the fp8 path serves spatial self-attention (mask 0) with 16-bit output");
   const int es = a->fp8 ? 1 : (a->dtype == TT_F32 ? 4 : 2);      // bytes per q/k/vt element
   const int eso = a->dtype == TT_F32 ? 4 : 2;
-  if (((a->ldq * es) & 15) || ((a->ldk * es) & 15) || ((a->ldvt * es) & 15) || ((a->ldo * eso) & 15) || ((a->v_seq_stride * es) & 15))
+  if ((a->q && ((a->ldq * es) & 15)) || ((a->ldk * es) & 15) || ((a->ldvt * es) & 15) || ((a->ldo * eso) & 15) || ((a->v_seq_stride * es) & 15))
     TT_FAIL(TT_EINVAL, "tt_attention: strides must keep 16-byte chunks aligned");
   AttnP p;
   p.q = (const char*)a->q; p.ldq = a->ldq; p.k = (const char*)a->k; p.ldk = a->ldk;
@@ -804,6 +942,13 @@ extern "C" int tt_attention(const TtAttnArgs* a, tt_stream_t stream) {
     p.k_bytes = (unsigned)kb; p.vt_bytes = (unsigned)vb;
   }
   p.scale_log2e = 1.4426950408889634f / sqrtf((float)a->head_dim);
+  p.qx = (const char*)a->qx; p.ldqx = a->ldqx; p.wq = (const char*)a->wq; p.ldwq = a->ldwq; p.bq = a->bq; p.qc = a->qc; p.ln_eps = a->ln_eps;
+  p.qx_bytes = p.wq_bytes = 0;
+  if (a->qx) {
+    const long xb = (((long)a->nseq * a->lq - 1) * a->ldqx + a->qc) * 2, wb = (((long)a->heads * 64 - 1) * a->ldwq + a->qc) * 2;
+    if (xb >= (1L << 31) || wb >= (1L << 31)) TT_FAIL(TT_EUNSUPPORTED, "tt_attention: x or Wq larger than 2 GiB");
+    p.qx_bytes = (unsigned)xb; p.wq_bytes = (unsigned)wb;
+  }
   hipStream_t st = (hipStream_t)stream;
   if (a->fp8) {
     if (a->dtype == TT_BF16) { if (a->head_dim == 64) launch_attn8<bf16_tag, 64>(p, st); else launch_attn8<bf16_tag, 128>(p, st); }

@@ -27,6 +27,10 @@
 #include <type_traits>
 #include "gemm_kernel.h"
 
+#ifndef TT_PP_GEGLU_STORE_AUX
+#define TT_PP_GEGLU_STORE_AUX 0      // cache policy of the GEGLU output stores (aux: 2 = nt); measured, see DESIGN.md 6.R4
+#endif
+
 namespace ttg {
 
 template <int N> __device__ __forceinline__ void pp_wait_vm() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
@@ -346,7 +350,7 @@ __global__ __launch_bounds__(512, 2) void gemm_pp_kernel(const GemmP p) {
         for (int ps = 0; ps < 2; ++ps) {
           const int gm = mb + ps * 16 + rr;
           __builtin_amdgcn_raw_buffer_store_b128((u32x4_t){tq[ps].x, tq[ps].y, tq[ps].z, tq[ps].w}, ro,
-                                                 (gm < p.m && oc * 2 < p.n) ? (int)(((long)gm * p.ldo + oc) * ES) : kInv, 0, 0);
+                                                 (gm < p.m && oc * 2 < p.n) ? (int)(((long)gm * p.ldo + oc) * ES) : kInv, 0, TT_PP_GEGLU_STORE_AUX);
         }
       }
       if constexpr (!ZERO_BY_MFMA) {

@@ -28,6 +28,10 @@
 #include <type_traits>
 #include "gemm_kernel.h"
 
+#ifndef TT_W320_A_AUX
+#define TT_W320_A_AUX 0      // cache policy of the A stream's LDS-DMA (aux: 2 = nt); measured: see DESIGN.md 6.R4
+#endif
+
 namespace ttg {
 
 template <int N> __device__ __forceinline__ void w3_wait_vm() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
@@ -257,9 +261,9 @@ __global__ __launch_bounds__(512, 2) void gemm_w320_kernel(const GemmP p) {
     char* dst = smem + slot * SLOT + I * 8192 + wid * 1024;
     const int v = p_ok ? a_off[I] : kInv;
     if (__builtin_amdgcn_readfirstlane(p_src))
-      __builtin_amdgcn_raw_ptr_buffer_load_lds(ra1, (__attribute__((address_space(3))) void*)dst, 16, v, p_soff_a, 0, 0);
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(ra1, (__attribute__((address_space(3))) void*)dst, 16, v, p_soff_a, 0, TT_W320_A_AUX);
     else
-      __builtin_amdgcn_raw_ptr_buffer_load_lds(ra0, (__attribute__((address_space(3))) void*)dst, 16, v, p_soff_a, 0, 0);
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(ra0, (__attribute__((address_space(3))) void*)dst, 16, v, p_soff_a, 0, TT_W320_A_AUX);
   };
   auto stage_w = [&](int slot, auto j_tag) {
     constexpr int J = decltype(j_tag)::value;
@@ -500,9 +504,9 @@ __global__ __launch_bounds__(512, 2) void gemm_w320h_kernel(const GemmP p) {
     char* dst = smem + slot * SLOT + I * 8192 + wid * 1024;
     const int v = p_ok ? a_off[I] : kInv;
     if (__builtin_amdgcn_readfirstlane(p_src))
-      __builtin_amdgcn_raw_ptr_buffer_load_lds(ra1, (__attribute__((address_space(3))) void*)dst, 16, v, p_soff_a, 0, 0);
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(ra1, (__attribute__((address_space(3))) void*)dst, 16, v, p_soff_a, 0, TT_W320_A_AUX);
     else
-      __builtin_amdgcn_raw_ptr_buffer_load_lds(ra0, (__attribute__((address_space(3))) void*)dst, 16, v, p_soff_a, 0, 0);
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(ra0, (__attribute__((address_space(3))) void*)dst, 16, v, p_soff_a, 0, TT_W320_A_AUX);
   };
   auto stage_w = [&](int slot, auto j_tag) {
     constexpr int J = decltype(j_tag)::value;

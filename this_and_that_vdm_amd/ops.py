@@ -195,11 +195,27 @@ def conv3x3(x0, x1, w, nimg: int, h: int, wd: int, *, gn=None, silu: bool = True
     return out
 
 
+# cross-attention with the query projection computed by the attention kernel itself (tt_attention, TtAttnArgs.qx): on by default,
+# TT_ATTN_QPROJ=0 keeps the separate LayerNorm-folded projection GEMM (A/B)
+ATTN_QPROJ = os.environ.get("TT_ATTN_QPROJ", "1") != "0"
+
+
+def attention_qproj_supported(x, head_dim: int, mask: int) -> bool:
+    return ATTN_QPROJ and mask != 0 and head_dim == 64 and x.dtype in (torch.float16, torch.bfloat16) and x.shape[-1] % 64 == 0 and \
+        x.stride(0) % 8 == 0 and x.stride(1) == 1
+
+
 def attention(q, k, vt, out, *, nseq, lq, heads, head_dim, mask, lk, k_seq_stride, v_seq_stride, frames=1, ctx_batches=1,
-              batch0=0):
+              batch0=0, qx=None, wq=None, bq=None, ln_eps: float = 1e-5):
+    """q [nseq*lq, heads*d] -- or q=None with qx / wq / bq: the kernel computes Q = LN(qx rows) wq^T + bq itself (cross-attention,
+    d = 64, 16-bit; wq / bq LayerNorm-folded and row-permuted by packing.permute_q_rows)."""
     lib = _lib.load()
     a = TtAttnArgs()
-    a.q, a.ldq = _p(q), q.stride(0)
+    if qx is not None:
+        a.qx, a.ldqx, a.wq, a.ldwq, a.bq, a.qc, a.ln_eps = _p(qx), qx.stride(0), _p(wq), wq.stride(0), _p(bq), qx.shape[1], float(ln_eps)
+        q = qx                                     # dtype / profiling below; a.q stays NULL
+    else:
+        a.q, a.ldq = _p(q), q.stride(0)
     a.k, a.ldk = _p(k), k.stride(0)
     a.vt, a.ldvt = _p(vt), vt.stride(0)
     a.out, a.ldo = _p(out), out.stride(0)
@@ -213,8 +229,9 @@ def attention(q, k, vt, out, *, nseq, lq, heads, head_dim, mask, lk, k_seq_strid
     check(lib.tt_attention(C.byref(a), _stream()), "tt_attention")
     if ev is not None:
         tag = _TAG[a.dtype]
-        kname = f"attn8_kernel<{tag}, {head_dim}>" if fp8 else f"attn_kernel<{tag}, {head_dim}, {mask}>"
-        _prof_end(ev, kname, 4.0 * nseq * heads * lq * lk * head_dim, shape=("attn", nseq * heads, lq, lk, mask, 0))
+        kname = f"attn8_kernel<{tag}, {head_dim}>" if fp8 else f"attn_kernel<{tag}, {head_dim}, {mask}{', true' if qx is not None else ''}>"
+        flops = 4.0 * nseq * heads * lq * lk * head_dim + (2.0 * nseq * lq * heads * head_dim * qx.shape[1] if qx is not None else 0.0)
+        _prof_end(ev, kname, flops, shape=("attn", nseq * heads, lq, lk, mask, 0))
     return out
 
 

@@ -100,3 +100,17 @@ def fold_layernorm(weight: torch.Tensor, bias, gamma: torch.Tensor, beta: torch.
     if bias is not None:
         b = b + bias.detach().float()
     return wc.contiguous(), b.contiguous()
+
+
+def permute_q_rows(t: torch.Tensor) -> torch.Tensor:
+    """Rows (output features) of a query projection -- weight [heads*64, C] or bias [heads*64] -- reordered for the fused query
+    projection of tt_attention (include/ttvdm.h, TtAttnArgs.qx): inside every group of 16 rows bits 2 and 3 of the row index are
+    swapped, new[n] = old[d(n)] with d(n) = n with bits 2 <-> 3 exchanged.  The projection's MFMA accumulators then hold, in
+    contraction slot s of lane half hi at key step ks, head dimension 16 ks + 8 hi + s -- what the K fragment of that step holds.
+    (An involution: applying it twice restores the order.)"""
+    n = t.shape[0]
+    if n % 16:
+        raise ValueError("permute_q_rows: row count must be a multiple of 16")
+    idx = torch.arange(n, device=t.device)
+    d = (idx & ~12) | ((idx & 4) << 1) | ((idx & 8) >> 1)
+    return t[d].contiguous()

@@ -19,7 +19,7 @@ import torch
 import torch.nn as nn
 
 from .. import ops
-from ..packing import fold_layernorm, pack_conv1x1, pack_conv3x3, pack_geglu, pack_tconv3, zero_sum_round
+from ..packing import fold_layernorm, pack_conv1x1, pack_conv3x3, pack_geglu, pack_tconv3, permute_q_rows, zero_sum_round
 
 
 ZERO_CTX_TEMPORAL = os.environ.get("TT_ZERO_CTX_T", "1") != "0"      # A/B switch of the temporal zero-context shortcut
@@ -481,15 +481,18 @@ def _self_attention(x, attn: Attention, wqk, bqk, wv, eps, g: Geom, ctx: StepCon
                          mask=0, lk=g.hw, k_seq_stride=g.hw, v_seq_stride=hwp)
 
 
-def _cross_attention(x, attn: Attention, wq, bq, eps, kv, g: Geom, ctx: StepContext, temporal: bool):
-    """cross-attention on the UN-normalised hidden states (norm2 folded into the query projection)."""
+def _cross_attention(x, attn: Attention, wq, bq, eps, kv, g: Geom, ctx: StepContext, temporal: bool, fused=None):
+    """cross-attention on the UN-normalised hidden states (norm2 folded into the query projection).  ``fused`` = (wq, bq) with the
+    rows permuted for the attention kernel's own query projection (packing.permute_q_rows): no Q tensor, no projection launch."""
     off, c = kv
+    mask = 2 if temporal else 1
+    out = torch.empty((g.m, c), dtype=x.dtype, device=x.device)
+    kw = dict(nseq=g.n, lq=g.hw, heads=attn.heads, head_dim=attn.dim_head, mask=mask, lk=ctx.s_ctx, k_seq_stride=ctx.s_pad,
+              v_seq_stride=ctx.s_pad, frames=g.frames, ctx_batches=g.ctx_batches, batch0=g.batch0)
+    if fused is not None and ops.attention_qproj_supported(x, attn.dim_head, mask):
+        return ops.attention(None, ctx.k_all[:, off:off + c], ctx.vt_all[off:off + c], out, qx=x, wq=fused[0], bq=fused[1], ln_eps=eps, **kw)
     q = ops.gemm(x, wq, bias=bq, ln_fold=1, ln_eps=eps)
-    x_norm = x
-    out = torch.empty((g.m, c), dtype=x_norm.dtype, device=x_norm.device)
-    return ops.attention(q, ctx.k_all[:, off:off + c], ctx.vt_all[off:off + c], out, nseq=g.n, lq=g.hw, heads=attn.heads,
-                         head_dim=attn.dim_head, mask=2 if temporal else 1, lk=ctx.s_ctx, k_seq_stride=ctx.s_pad,
-                         v_seq_stride=ctx.s_pad, frames=g.frames, ctx_batches=g.ctx_batches, batch0=g.batch0)
+    return ops.attention(q, ctx.k_all[:, off:off + c], ctx.vt_all[off:off + c], out, **kw)
 
 
 class BasicTransformerBlock(_Packable):
@@ -521,6 +524,7 @@ class BasicTransformerBlock(_Packable):
         self.bo1 = (_f32(self.attn1.to_out[0].bias) + self.wo1.float() @ bv).contiguous()
         wq2, self.bq2 = fold_layernorm(self.attn2.to_q.weight, None, n2.weight, n2.bias)
         self.wq2 = zr(wq2)
+        self.q2_fused = (permute_q_rows(self.wq2), permute_q_rows(self.bq2.contiguous())) if self.attn2.dim_head == 64 else None
         self.wo2, self.bo2 = cv(self.attn2.to_out[0].weight), _f32(self.attn2.to_out[0].bias)
         self.kv = reg.add_kv(self.attn2.to_k, self.attn2.to_v)
         self.ff.pack(reg, dtype, norm=self.norm3)
@@ -547,7 +551,7 @@ class BasicTransformerBlock(_Packable):
         live = ctx.live_batches(g)
         if live is None:
             x = ops.gemm(a, self.wo1, bias=self.bo1, residual=x)
-            a = _cross_attention(x, self.attn2, self.wq2, self.bq2, self.norm2.eps, self.kv, g, ctx, temporal=False)
+            a = _cross_attention(x, self.attn2, self.wq2, self.bq2, self.norm2.eps, self.kv, g, ctx, temporal=False, fused=self.q2_fused)
             x = ops.gemm(a, self.wo2, bias=self.bo2, residual=x)
             return self.ff(x, residual=x, **ff_rv)
         # Batch elements with an all-zero context (the CFG uncond half): K = V = 0, so their cross-attention output is exactly 0
@@ -560,7 +564,7 @@ class BasicTransformerBlock(_Packable):
             rows = g.frames * g.hw
             xs = x[first * rows:(first + count) * rows]
             gl = Geom(count, g.frames, g.h, g.w, g.batch0 + first, g.ctx_batches)
-            a = _cross_attention(xs, self.attn2, self.wq2, self.bq2, self.norm2.eps, self.kv, gl, ctx, temporal=False)
+            a = _cross_attention(xs, self.attn2, self.wq2, self.bq2, self.norm2.eps, self.kv, gl, ctx, temporal=False, fused=self.q2_fused)
             ops.gemm(a, self.wo2, bias=self.bo2, residual=xs, out=xs)
         return self.ff(x, residual=x, **ff_rv)
 
@@ -595,6 +599,7 @@ class TemporalBasicTransformerBlock(_Packable):
         self.wo1, self.bo1 = cv(self.attn1.to_out[0].weight), _f32(self.attn1.to_out[0].bias)
         wq2, self.bq2 = fold_layernorm(self.attn2.to_q.weight, None, n2.weight, n2.bias)
         self.wq2 = zr(wq2)
+        self.q2_fused = (permute_q_rows(self.wq2), permute_q_rows(self.bq2.contiguous())) if self.attn2.dim_head == 64 else None
         self.wo2, self.bo2 = cv(self.attn2.to_out[0].weight), _f32(self.attn2.to_out[0].bias)
         self.bo12 = (self.bo1 + self.bo2).contiguous()      # rows whose cross-attention context is all zeros (forward)
         self.kv = reg.add_kv(self.attn2.to_k, self.attn2.to_v)
@@ -619,7 +624,7 @@ class TemporalBasicTransformerBlock(_Packable):
         live = ctx.live_classes(g)
         if live is None:
             t = ops.gemm(a, self.wo1, bias=self.bo1, residual=t)
-            a = _cross_attention(t, self.attn2, self.wq2, self.bq2, self.norm2.eps, self.kv, g, ctx, temporal=True)
+            a = _cross_attention(t, self.attn2, self.wq2, self.bq2, self.norm2.eps, self.kv, g, ctx, temporal=True, fused=self.q2_fused)
             t = ops.gemm(a, self.wo2, bias=self.bo2, residual=t)
         else:
             # Rows of a residue class whose context is all zeros (the CFG uncond context: every other pixel, quirk Q3) get
@@ -642,12 +647,16 @@ class TemporalBasicTransformerBlock(_Packable):
             for cls in range(cb):
                 tv = t[cls::cb]
                 if cls in live:
-                    q = ops.gemm(tv, self.wq2, bias=self.bq2, ln_fold=1, ln_eps=self.norm2.eps)
-                    a = torch.empty_like(q)
                     # every sequence of this class uses context `cls`: mask 1 with one "batch" spanning all sequences
-                    ops.attention(q, ctx.k_all[:, off:off + cc], ctx.vt_all[off:off + cc], a, nseq=g.n, lq=g.hw // cb,
-                                  heads=self.attn2.heads, head_dim=self.attn2.dim_head, mask=1, lk=ctx.s_ctx, k_seq_stride=ctx.s_pad,
-                                  v_seq_stride=ctx.s_pad, frames=g.n, ctx_batches=cb, batch0=cls)
+                    akw = dict(nseq=g.n, lq=g.hw // cb, heads=self.attn2.heads, head_dim=self.attn2.dim_head, mask=1, lk=ctx.s_ctx,
+                               k_seq_stride=ctx.s_pad, v_seq_stride=ctx.s_pad, frames=g.n, ctx_batches=cb, batch0=cls)
+                    a = torch.empty((tv.shape[0], c), dtype=tv.dtype, device=tv.device)
+                    if self.q2_fused is not None and ops.attention_qproj_supported(tv, self.attn2.dim_head, 1):
+                        ops.attention(None, ctx.k_all[:, off:off + cc], ctx.vt_all[off:off + cc], a, qx=tv, wq=self.q2_fused[0],
+                                      bq=self.q2_fused[1], ln_eps=self.norm2.eps, **akw)
+                    else:
+                        q = ops.gemm(tv, self.wq2, bias=self.bq2, ln_fold=1, ln_eps=self.norm2.eps)
+                        ops.attention(q, ctx.k_all[:, off:off + cc], ctx.vt_all[off:off + cc], a, **akw)
                     ops.gemm(a, self.wo2, bias=self.bo2, residual=tv, out=tv)
             side.join()
             del a_self
