@@ -198,3 +198,30 @@ def test_folded_layernorm_weights_keep_zero_row_sums_after_rounding(dtype):
     rstd = 1.0 / torch.sqrt(x.var(1, unbiased=False, keepdim=True) + 1e-5)
     err = lambda wq: float(((rstd * (x.double() @ wq.double().T) + bf) - ref).abs().max())
     assert err(zs) < err(plain) / 10 and err(zs) < 0.05, (err(zs), err(plain))
+
+
+def test_query_row_permutation_matches_the_mfma_operand_slots():
+    """packing.permute_q_rows (the fused query projection of tt_attention, include/ttvdm.h TtAttnArgs.qx): the projection's MFMA
+    accumulators are used as the Q^T operand of the score product.  In the accumulator layout lane half `hi` of fragment j holds
+    output columns n = 32 j + 8 g + 4 hi + e; registers g = 2t, 2t+1 are the 8 contraction slots s = 4 (g - 2t) + e of key step
+    ks = 2j + t, and slot s of half hi must be head dimension 16 ks + 8 hi + s (what the K fragment read supplies).  So row n of
+    the permuted weight has to be original row d(n) -- checked for every (j, t, hi, s) of a 64-wide head, plus: involution, a
+    permutation inside every 16-row group, applied identically to weight rows and bias entries."""
+    import torch
+    from this_and_that_vdm_amd.packing import permute_q_rows
+    heads, d = 3, 64
+    ident = torch.arange(heads * d)
+    perm = permute_q_rows(ident)                      # perm[n] = d(n)
+    assert torch.equal(permute_q_rows(perm), ident)
+    assert torch.equal(perm.view(-1, 16).sort(1).values, ident.view(-1, 16))
+    for h in range(heads):
+        for j in range(2):
+            for t in range(2):
+                for hi in range(2):
+                    for s_ in range(8):
+                        g, e = 2 * t + s_ // 4, s_ % 4
+                        n = h * d + 32 * j + 8 * g + 4 * hi + e
+                        assert int(perm[n]) == h * d + 16 * (2 * j + t) + 8 * hi + s_, (h, j, t, hi, s_)
+    w = torch.randn(heads * d, 40)
+    b = torch.randn(heads * d)
+    assert torch.equal(permute_q_rows(w), w[perm]) and torch.equal(permute_q_rows(b), b[perm])

@@ -268,3 +268,27 @@ def test_captured_graphs_survive_scratch_growth_and_weight_reloads():
     assert torch.equal(after, eager), "re-captured graph must equal eager launches on the new weights"
     p_unet.load_state_dict(sd)
     assert torch.equal(vl.begin(**kw(8, 16, False)).run(), before), "restoring the weights restores the result"
+
+
+@torch.no_grad()
+def test_film_table_rows_are_the_per_step_film_rows_bit_for_bit():
+    """DenoiserBase.film_table (round 4): the time embedding + FiLM rows of all steps of a request evaluated at once must equal,
+    bit for bit, what the per-step path computes inside the graph (_embed + _step_context) for every step and both models --
+    including a CFG batch of 3 (10 steps per launch) and more rows than one launch holds (25 steps x 2 = 50 rows)."""
+    if not torch.cuda.is_available():
+        pytest.skip("needs a GPU")
+    from tests.parity_common import build_pair
+    from this_and_that_vdm_amd.svd.scheduling_euler_discrete import EulerDiscreteScheduler
+    p_unet, p_cn, _, _ = build_pair("tiny_vgl", torch.float16, "cuda:0", True)
+    sched = EulerDiscreteScheduler()
+    sched.set_timesteps(25)
+    for model in (p_unet, p_cn):
+        model.prepare()
+        for batch in (1, 2, 3):
+            ids = torch.tensor([[6.0, 127.0, 0.02]] * batch, device="cuda")
+            tab = model.film_table(sched.timesteps, ids, batch)
+            assert tab.shape[:2] == (25, batch) and tab.dtype == torch.float32
+            for i in (0, 7, 24):
+                t = sched.timesteps[i:i + 1].to("cuda", torch.float32)
+                ctx = model._step_context(model._embed(t, ids, batch, torch.device("cuda:0")), (None, None, 0, 0, 0))
+                assert torch.equal(tab[i], ctx.film), (type(model).__name__, batch, i)
