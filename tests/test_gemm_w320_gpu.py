@@ -55,6 +55,7 @@ def same_as_tiled(out, tiled, dtype):
 
 @pytest.mark.parametrize("dtype", DTYPES16)
 @pytest.mark.parametrize("m,n,k", [(46100, 320, 192), (50176, 640, 128), (50176 - 250, 960, 128),
+                                   (200704 - 100, 320, 128),                                          # 784 tiles: four rounds of workgroups (64x112 latents)
                                    (12500, 640, 192), (25088 - 60, 320, 128), (12544, 1920, 128)])     # the last three: 128-row tiles
 def test_linear_full_epilogue(ops, dtype, m, n, k):
     """bias, scale, row vector (groups of 3000 rows: a fragment row can straddle two), residual and a DISTINCT blend tensor;
