@@ -112,14 +112,17 @@ int tt_gemm_set_tile_override(int32_t cfg);
  * the persistent W-in-registers streaming kernel.  Off by default (faster alone, slower next to a concurrent branch);
  * also settable by TT_GEMM_SQ320=1. */
 int tt_gemm_set_streaming_square(int32_t on);
-/* tuning knob for the N = 320 t big-tile kernels (gemm_w320.hip), for A/B measurements and tests; also TT_GEMM_W320=0|1|2|3:
+/* tuning knob for the N = 320 t big-tile kernels (gemm_w320.hip), for A/B measurements and tests; also TT_GEMM_W320=0|1|2|3|4:
  *   0  keep these problems on the tiled kernels;
  *   1  (default) problems with >= 180 row tiles of 256 (the finest UNet level: ResnetBlock2D / temporal convs, shortcuts, proj_in/out,
  *      to_out, FF2, LayerNorm-folded Q projections -- svd/diffusion_arch/unet_3d_blocks.py:2094,2212,2311,
  *      svd/diffusion_arch/transformer_temporal.py:323-376) go to the 256 x 320 kernel; conv3x3 problems with fewer rows but >= 180
  *      tiles of 128 rows (the second level at 32x56 latents) to its 128 x 320 variant (measured: +9..16 % on those convs, nothing
- *      on the linears / temporal convs of that level, which therefore stay on the tiled kernels);
- *   2  the 256 x 320 kernel only;    3  the 128 x 320 variant for every gather mode (its linear / temporal-conv / LayerNorm paths). */
+ *      on the linears / temporal convs of that level, which therefore stay on the tiled kernels); long-K problems of the two
+ *      coarsest levels (FF2 at 3136 rows, conv3x3 at 3136 / 784 rows: 100 / 28 tiles of 128 x 320) go to the variant with the K
+ *      loop split over 2..16 workgroups per tile (fp32 slabs in the tt_gemm_ws_bytes workspace, summed in a fixed order);
+ *   2  the 256 x 320 kernel only;    3  the 128 x 320 variant for every gather mode (its linear / temporal-conv / LayerNorm paths);
+ *   4  as 1 without the split-K route. */
 int tt_gemm_set_big_tile(int32_t on);
 
 /* ------------------------------------------------------------------------------------------------

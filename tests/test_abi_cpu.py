@@ -133,3 +133,54 @@ def test_gemm_dispatch_rules_of_the_big_tile_kernel(lib):
     finally:
         lib.tt_gemm_set_big_tile(1)
     assert plan(50176, 320, 1280)[0] == w320 and plan(12544, 640, 640, **l1conv)[0] == w320h and plan(25088, 320, 320)[0] != w320h
+
+
+def test_gemm_dispatch_rules_of_the_split_k_big_tile_route(lib):
+    """tt_gemm_plan / tt_gemm_ws_bytes, host-only: the 128 x 320 kernel with S K-slices per tile (cfg[6] = S) takes the 3x3 convs
+    of the third level (3136 rows at 32x56 latents) when the caller supplies the workspace; tt_gemm_set_big_tile(3) opens the route to
+    Linear problems and the 28-tile level (measured +-0 there: off by default)."""
+    import ctypes as C
+    from this_and_that_vdm_amd import ops
+
+    def args(m, n, k, **kw):
+        g = _lib.TtGemmArgs()
+        g.m, g.n, g.k0, g.mode, g.dtype = m, n, k, 0, ops.TT_BF16
+        g.lda0, g.ldw, g.ldo = k, k, n
+        g.ln_eps = 1e-5
+        for name, v in kw.items():
+            setattr(g, name, v)
+        return g
+
+    def plan(m, n, k, ws=True, **kw):
+        g = args(m, n, k, **kw)
+        need = lib.tt_gemm_ws_bytes(C.byref(g))
+        if ws and need:
+            g.ws, g.ws_bytes = 256, need                      # a fake (aligned) pointer: the plan only looks at its presence and size
+        cfg = (C.c_int32 * 7)()
+        assert lib.tt_gemm_plan(C.byref(g), cfg) == 0
+        return list(cfg), need
+
+    split = lambda s: [128, 320, 64, 0, 2, 2, s]
+    conv = lambda hh, ww: dict(mode=1, nimg=28, hin=hh, win=ww, hout=hh, wout=ww, stride=1, upsample=0)
+    assert plan(3136, 1280, 1280, **conv(8, 14)) == (split(2), 2 * 3136 * 1280 * 4)                 # conv3x3 of the third level: 100 tiles x 2 slices
+    assert plan(3136, 1280, 1280, k1=1280, lda1=1280, **conv(8, 14))[0] == split(2)
+    assert plan(3136, 1280, 1280, ws=False, **conv(8, 14))[0][:2] == [128, 128]                    # no workspace: an un-split tiled plan
+    assert plan(3136, 1280, 5120, residual=16, ld_res=1280)[0][:2] == [128, 128]                   # FF2: measured +-0, stays tiled by default
+    assert plan(784, 1280, 1280, **conv(4, 7))[0][:2] == [128, 128]                                # 28 tiles: measured +-0, stays tiled by default
+    assert plan(3136, 1280, 64, **conv(8, 14))[0][:2] == [128, 128]                                # 9 slabs: too short for two slices
+    assert plan(12544, 640, 640, **conv(16, 28))[0] == [128, 320, 64, 0, 2, 2, 1]                  # the second level: 196 tiles, no slices
+    try:
+        assert lib.tt_gemm_set_big_tile(3) == 0                                                    # the variant for every mode: Linear and the 28-tile level too
+        assert plan(3136, 1280, 5120, residual=16, ld_res=1280) == (split(2), 2 * 3136 * 1280 * 4)
+        assert plan(784, 1280, 1280, **conv(4, 7)) == (split(9), 9 * 784 * 1280 * 4)               # 28 tiles x 9 slices of 20 slabs
+        assert plan(784, 1280, 1280, k1=1280, lda1=1280, **conv(4, 7))[0] == split(9)
+        assert plan(3136, 1280, 2560)[0][1] != 320                                                 # 40 slabs: too short for two slices
+        assert plan(784, 1280, 5120)[0][1] != 320                                                  # 28 tiles x 2 slices would leave the chip empty
+        assert plan(3136, 1280, 3840, mode=2, frames=14, hw=112)[0][1] != 320                      # temporal conv: never split
+        assert plan(3136, 1280, 5120, ln_fold=1)[0][1] != 320                                      # a K slice would see part of a LayerNorm row
+        assert lib.tt_gemm_set_big_tile(4) == 0                                                    # everything of round 4 but the split-K route
+        assert plan(3136, 1280, 1280, **conv(8, 14))[0][:2] == [128, 128]
+        assert plan(50176, 320, 1280)[0][:2] == [256, 320]
+    finally:
+        lib.tt_gemm_set_big_tile(1)
+    assert plan(3136, 1280, 1280, **conv(8, 14))[0] == split(2)

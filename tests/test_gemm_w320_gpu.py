@@ -221,3 +221,93 @@ def test_planner_keeps_other_problems_off_the_big_tile(ops):
     assert not name_of(z(50176 * 4, 64), z(320, 9 * 64), mode=1, conv=(28, 64, 112, 32, 56, 2, 0)).startswith("gemm_w320")   # stride 2
     assert not name_of(torch.zeros(50176, 128, device="cuda"), torch.zeros(320, 128, device="cuda")).startswith("gemm_w320")  # TT_F32
     assert not name_of(z(50176, 128), z(640, 128), geglu=True).startswith("gemm_w320")
+
+
+# ---- split-K route of the 128-row kernel (the two coarsest UNet levels: 100 / 28 tiles of 128 x 320, S workgroups per tile)
+@pytest.mark.parametrize("dtype", DTYPES16)
+@pytest.mark.parametrize("m,n,k", [(3136, 1280, 5120), (3000, 1280, 4160), (1600, 1920, 6144)])
+def test_split_k_linear_full_epilogue(ops, dtype, m, n, k):
+    """FF2 of the third level (3136 rows, K = 5120: two K slices of 40 slabs), a ragged row count with an odd slab count
+    (65 slabs: 32 + 33), 13 row tiles x 6 column tiles in three slices; every epilogue operand goes through splitk_epilogue_kernel."""
+    a, w = rnd(m, k, dtype=dtype, seed=1), rnd(n, k, dtype=dtype, seed=2, scale=k ** -0.5)
+    bias = rnd(n, dtype=torch.float32, seed=3)
+    rows_per = 1000
+    rowvec = rnd((m + rows_per - 1) // rows_per, n, dtype=torch.float32, seed=4)
+    res, bl = rnd(m, n, dtype=dtype, seed=5), rnd(m, n, dtype=dtype, seed=6)
+    kw = dict(bias=bias.cuda(), acc_scale=0.75, rowvec=rowvec.cuda(), rowvec_rows=rows_per, residual=res.cuda(), blend=bl.cuda(), alpha=0.3)
+    out, tiled, name = both(ops, a.cuda(), w.cuda(), **kw)
+    assert name.startswith("gemm_w320h_kernel<") and name.endswith(", 0, 0>"), name
+    ref = (a.float() @ w.float().T + bias) * 0.75 + rowvec.repeat_interleave(rows_per, 0)[:m] + res.float()
+    ref = 0.3 * bl.float() + 0.7 * ref
+    close(out, ref, dtype, scale=2.0)
+    same_as_tiled(out, tiled, dtype)
+
+
+@pytest.mark.parametrize("dtype", DTYPES16)
+@pytest.mark.parametrize("h,w,c0,c1,cout", [(8, 14, 128, 320, 1280),      # 63 slabs in two slices: the second one starts inside tap 4, in the SECOND source
+                                            (8, 13, 320, 0, 1280),       # 2912 rows: ragged last row tile; 45 slabs, 22 + 23
+                                            (4, 7, 640, 640, 1280)])     # the coarsest level: 28 tiles x 9 slices of 20 slabs (one tap each)
+def test_split_k_conv3x3(ops, dtype, h, w, c0, c1, cout):
+    """3x3 convs of the third and fourth level through the split-K route: the K walk of a slice starts at an arbitrary
+    (tap, source, k step); bias + FiLM row + residual in the second pass."""
+    from this_and_that_vdm_amd.packing import pack_conv3x3
+    nimg, frames = 28, 14
+    x0 = rnd(nimg, c0, h, w, dtype=dtype, seed=1)
+    x1 = rnd(nimg, c1, h, w, dtype=dtype, seed=2) if c1 else None
+    c = c0 + c1
+    wt = rnd(cout, c, 3, 3, dtype=dtype, seed=3, scale=(9 * c) ** -0.5)
+    bias = rnd(cout, dtype=torch.float32, seed=4)
+    film = rnd(nimg // frames, cout, dtype=torch.float32, seed=7)
+    res = rnd(nimg * h * w, cout, dtype=dtype, seed=8)
+    xin = torch.cat([x0, x1], 1).float() if c1 else x0.float()
+    ref = F.conv2d(xin, wt.float(), bias, padding=1).permute(0, 2, 3, 1).reshape(-1, cout)
+    ref = ref + film.repeat_interleave(frames * h * w, 0) + res.float()
+    tok = lambda t: t.permute(0, 2, 3, 1).reshape(-1, t.shape[1]).contiguous().cuda()
+    kw = dict(a1=tok(x1) if c1 else None, mode=1, conv=(nimg, h, w, h, w, 1, 0), bias=bias.cuda(), rowvec=film.cuda(),
+              rowvec_rows=frames * h * w, residual=res.cuda())
+    out, tiled, name = both(ops, tok(x0), pack_conv3x3(wt).cuda(), **kw)
+    assert name.startswith("gemm_w320h_kernel<") and name.endswith(", 1, 0>"), name
+    close(out, ref, dtype, scale=2.0)
+    same_as_tiled(out, tiled, dtype)
+
+
+def test_split_k_is_deterministic_and_in_place(ops):
+    """the slabs are summed in a fixed order: two runs agree bit for bit; the second pass may write over its residual."""
+    dtype = torch.bfloat16
+    m, n, k = 3136, 1280, 5120
+    a, w = rnd(m, k, dtype=dtype, seed=1).cuda(), rnd(n, k, dtype=dtype, seed=2, scale=k ** -0.5).cuda()
+    x = rnd(m, n, dtype=dtype, seed=5).cuda()
+    bias = rnd(n, dtype=torch.float32, seed=3).cuda()
+    lib = ops._lib.load()
+    lib.tt_gemm_set_big_tile(3)                           # Linear problems take the split-K route under this knob only
+    try:
+        o1 = ops.gemm(a, w, bias=bias, residual=x)
+        o2 = ops.gemm(a, w, bias=bias, residual=x)
+        assert torch.equal(o1, o2)
+        ops.PROFILE = []
+        ops.gemm(a, w, bias=bias, residual=x, out=x)
+        torch.cuda.synchronize()
+        name = ops.PROFILE[0][0]
+        ops.PROFILE = None
+    finally:
+        lib.tt_gemm_set_big_tile(1)
+    assert name.startswith("gemm_w320h_kernel<"), name
+    assert torch.equal(x, o1)
+
+
+def test_split_k_default_route_is_the_third_level_conv(ops):
+    """without any knob: the 3x3 conv at 3136 rows runs on the split-K route, FF2 of the same level and the 784-row conv do not."""
+    dt = torch.bfloat16
+    z = lambda *s: torch.zeros(*s, dtype=dt, device="cuda")
+
+    def name_of(a, w, **kw):
+        ops.PROFILE = []
+        ops.gemm(a, w, **kw)
+        torch.cuda.synchronize()
+        n = ops.PROFILE[0][0]
+        ops.PROFILE = None
+        return n
+
+    assert name_of(z(3136, 1280), z(1280, 9 * 1280), mode=1, conv=(28, 8, 14, 8, 14, 1, 0)).startswith("gemm_w320h_kernel<")
+    assert not name_of(z(3136, 5120), z(1280, 5120)).startswith("gemm_w320")
+    assert not name_of(z(784, 1280), z(1280, 9 * 1280), mode=1, conv=(28, 4, 7, 4, 7, 1, 0)).startswith("gemm_w320")

@@ -176,23 +176,38 @@ bool pp_ok(const TtGemmArgs* a) {
 // rows) / residual / AlphaBlender epilogues.  TT_GEMM_W320=0 keeps them on the tiled kernels (A/B).
 static int g_w320 = -1;
 extern "C" int tt_gemm_set_big_tile(int32_t on) {
-  g_w320 = on == 0 ? 0 : (on == 2 ? 1 : (on == 3 ? 3 : 7));  // internal: bit 0 the 256 x 320 kernel, bit 1 its 128 x 320 variant, bit 2: that one for conv3x3 only
+  // internal: bit 0 the 256 x 320 kernel, bit 1 its 128 x 320 variant, bit 2: that one for conv3x3 only, bit 3: its split-K route
+  g_w320 = on == 0 ? 0 : (on == 2 ? 1 : (on == 3 ? 11 : (on == 4 ? 7 : 15)));
   return TT_OK;
+}
+static void w320_init() {
+  if (g_w320 < 0) { const char* e = getenv("TT_GEMM_W320"); tt_gemm_set_big_tile(e ? atoi(e) : 1); }
+}
+// what both kernels of gemm_w320.hip need of a problem
+static bool w320_eligible(const TtGemmArgs* a) {
+  w320_init();
+  if (!g_w320 || forced_cfg() >= 0 || a->dtype == TT_F32 || a->n % 320 || (a->k0 & 63) || (a->k1 & 63) || (a->mode == 1 ? 9 : a->mode == 2 ? 3 : 1) * (a->k0 + a->k1) < 128 || a->geglu ||
+      a->out_fp8 || a->out_f32 || a->out_col_hw || a->ln_fold > 1 || (a->ln_fold && (a->mode != 0 || a->k1)))
+    return false;
+  if (a->mode == 1 && (a->stride != 1 || a->upsample || a->hin != a->hout || a->win != a->wout || a->win >= 32768 || a->hin >= 32768)) return false;
+  if (a->rowvec && a->rowvec_rows < 32) return false;
+  // 8-byte (16-bit operands) / 16-byte (fp32 vectors) epilogue accesses
+  if ((a->ldo & 3) || (a->residual && (a->ld_res & 3)) || (a->blend && (a->ld_blend & 3)) || (a->rowvec && (a->ld_rowvec & 3))) return false;
+  if ((((size_t)a->out | (size_t)a->residual | (size_t)a->blend) & 7) || (((size_t)a->rowvec | (size_t)a->bias) & 15)) return false;
+  return true;
+}
+static int w320_force() {                                    // tuning aid: TT_W320_FORCE=1|2 routes every eligible problem to the 256- / 128-row kernel whatever the fill
+  static int force = -1;
+  if (force < 0) { const char* e = getenv("TT_W320_FORCE"); force = e ? atoi(e) : 0; }
+  return force;
 }
 // 0: not served; 1: 256 x 320 tiles (gemm_w320_kernel); 2: 128 x 320 tiles (gemm_w320h_kernel: problems whose 256-row tiles would fill
 // less than 70 % of a round, e.g. the second UNet level at 32x56 latents -- 12544 rows, N = 640: 98 x 2 = 196 tiles of 128 rows).
 // By default the variant takes conv3x3 problems only: A/B in the step 31.06 (256-row kernel only) / 31.01 (variant for all modes) /
 // 30.84 ms (variant for the convs); in isolation +9..16 % on the convs, +-0 on the linears and temporal convs (tools/w320_bench.py).
 int w320_route(const TtGemmArgs* a) {
-  if (g_w320 < 0) { const char* e = getenv("TT_GEMM_W320"); tt_gemm_set_big_tile(e ? atoi(e) : 1); }
-  if (!g_w320 || forced_cfg() >= 0 || a->dtype == TT_F32 || a->n % 320 || (a->k0 & 63) || (a->k1 & 63) || (a->mode == 1 ? 9 : a->mode == 2 ? 3 : 1) * (a->k0 + a->k1) < 128 || a->geglu ||
-      a->out_fp8 || a->out_f32 || a->out_col_hw || a->ln_fold > 1 || (a->ln_fold && (a->mode != 0 || a->k1)))
-    return 0;
-  if (a->mode == 1 && (a->stride != 1 || a->upsample || a->hin != a->hout || a->win != a->wout || a->win >= 32768 || a->hin >= 32768)) return 0;
-  if (a->rowvec && a->rowvec_rows < 32) return 0;
-  // 8-byte (16-bit operands) / 16-byte (fp32 vectors) epilogue accesses
-  if ((a->ldo & 3) || (a->residual && (a->ld_res & 3)) || (a->blend && (a->ld_blend & 3)) || (a->rowvec && (a->ld_rowvec & 3))) return 0;
-  if ((((size_t)a->out | (size_t)a->residual | (size_t)a->blend) & 7) || (((size_t)a->rowvec | (size_t)a->bias) & 15)) return 0;
+  if (!w320_eligible(a)) return 0;
+  if (w320_force() == 1 || w320_force() == 2) return w320_force();
   for (int half = 0; half < 2; ++half) {
     if (half && (!(g_w320 & 2) || ((g_w320 & 4) && a->mode != 1))) break;     // tt_gemm_set_big_tile(2): the 256-row kernel only
     const long tiles = (long)ceil_div(a->m, half ? 128 : 256) * (a->n / 320);
@@ -201,7 +216,28 @@ int w320_route(const TtGemmArgs* a) {
   }
   return 0;
 }
+// Split-K route of the 128 x 320 kernel for the coarse UNet levels (3136 / 784 rows at 32x56 latents: 100 / 28 tiles), where no tile
+// shape fills the chip and the tiled 128 x 128 kernel keeps the matrix pipe 35 % busy (profiles/r4_gemm_sq_counters.txt): S workgroups
+// per tile, each with >= 20 (conv3x3) / 32 (Linear) slabs of K, at most 256 workgroups and at least 160; the fp32 slabs are summed in a
+// fixed order by splitk_epilogue_kernel.  Returns S (0: not served).  Measured (tools/w320_split_probe.py, us, tiled -> split):
+//   conv3x3 at 3136 rows, 1280 / 1920 / 2560 -> 1280 channels   129.7 -> 108.5   173.2 -> 145.3   231.0 -> 190.3   (S = 2)
+//   FF2 at 3136 rows (K = 5120, S = 2) 64.2 -> 63.5;   conv3x3 at 784 rows (S = 9) 46.4 -> 47.1, 79.7 -> 75.6
+// -- the second pass and the fp32 slabs cost ~25 us per problem, so by default only the 3x3 convs with >= 64 tiles take the route;
+// tt_gemm_set_big_tile(3) opens it to the Linear problems and the 28-tile level as well (tests, A/B).
+int w320_split(const TtGemmArgs* a) {
+  if (!w320_eligible(a) || !(g_w320 & 8) || a->ln_fold || a->mode == 2 || w320_route(a)) return 0;
+  const long tiles = (long)ceil_div(a->m, 128) * (a->n / 320);
+  if ((g_w320 & 4) && (a->mode != 1 || tiles < 64)) return 0;
+  const long slabs = (long)(a->mode == 1 ? 9 : 1) * (a->k0 + a->k1) / 64;
+  long s = 256 / tiles;
+  const long by_k = slabs / (a->mode == 1 ? 20 : 32);
+  if (s > by_k) s = by_k;
+  if (s > 16) s = 16;
+  if (s < 2 || tiles * s < 160 || s * a->m * a->n * 4 >= (1L << 31)) return 0;
+  return (int)s;
+}
 bool w320_ok(const TtGemmArgs* a) { return w320_route(a) != 0; }
+static bool ws_fits(const TtGemmArgs* a, int split) { return a->ws && (size_t)a->ws_bytes >= (size_t)split * a->m * a->n * sizeof(float); }
 // rows the persistent kernel takes when the problem is launched in two parts (0: one launch)
 static int pp_split_rows(const TtGemmArgs* a) {
   if ((a->m & 255) == 0 || a->m < 512 || pp_ok(a)) return 0;
@@ -248,6 +284,12 @@ extern "C" int tt_gemm_plan(const TtGemmArgs* a, int32_t cfg[7]) {
     cfg[0] = route == 1 ? 256 : 128; cfg[1] = 320; cfg[2] = 64; cfg[3] = 0; cfg[4] = route == 1 ? 4 : 2; cfg[5] = 2; cfg[6] = 1;
     return TT_OK;
   }
+  if (const int split = w320_split(a)) {          // ... its split-K route (needs the workspace, like every split plan below)
+    if (ws_fits(a, split)) {
+      cfg[0] = 128; cfg[1] = 320; cfg[2] = 64; cfg[3] = 0; cfg[4] = 2; cfg[5] = 2; cfg[6] = split;
+      return TT_OK;
+    }
+  }
   Plan pl = plan_for(a);
   if (pl.splitk > 1 && (!a->ws || (size_t)a->ws_bytes < (size_t)pl.splitk * a->m * a->n * sizeof(float) ||
                         (long)pl.splitk * a->m * a->n * 4 >= (1L << 31)))
@@ -262,6 +304,7 @@ extern "C" size_t tt_gemm_ws_bytes(const TtGemmArgs* a) {
   if (pp_ok(a)) return 0;
   if (!pp_split_rows(a) && (sq320_ok(a) || w320_ok(a))) return 0;
   if (const int rows = pp_split_rows(a)) { TtGemmArgs head, tail; pp_split(a, rows, &head, &tail); return tt_gemm_ws_bytes(&tail); }
+  if (const int split = w320_split(a)) return (size_t)split * a->m * a->n * sizeof(float);
   const Plan pl = plan_for(a);
   return pl.splitk > 1 ? (size_t)pl.splitk * a->m * a->n * sizeof(float) : 0;
 }
@@ -349,6 +392,14 @@ extern "C" int tt_gemm(const TtGemmArgs* a, tt_stream_t stream) {
     else { if (a->dtype == TT_BF16) launch_w320h_bf16(p, st); else launch_w320h_f16(p, st); }
     TT_CHECK_LAUNCH("tt_gemm");
     return TT_OK;
+  }
+  if (const int split = w320_split(a)) {
+    if (ws_fits(a, split)) {                      // (no workspace: the tiled kernels' un-split plan below)
+      p.splitk = split; p.ws = (float*)a->ws; p.ws_bytes = (unsigned)((long)split * a->m * a->n * 4); p.group_m_override = 0; p.group_m = 1;
+      if (a->dtype == TT_BF16) launch_w320h_bf16(p, st); else launch_w320h_f16(p, st);
+      TT_CHECK_LAUNCH("tt_gemm");
+      return TT_OK;
+    }
   }
   Plan pl = plan_for(a);
   if (pl.splitk > 1 && (!a->ws || (size_t)a->ws_bytes < (size_t)pl.splitk * a->m * a->n * sizeof(float)))

@@ -180,6 +180,49 @@ __device__ __forceinline__ void w3_epilogue_dispatch(const GemmP& p, const f32x1
 #undef W3_RUN
 }
 
+// ---- split-K form of the above for ONE fragment row of gemm_w320h_kernel (p.splitk > 1): the fp32 partial sums of K slice `split`
+// (after the exchange of the two in-slab K halves) go to the workspace slab ws[split][m][n] through the same strip transposition,
+// 16 bytes per lane and 4 rows x 256 contiguous bytes per store instruction; splitk_epilogue_kernel (gemm_kernel.h) adds the slabs
+// in a fixed order and runs the full epilogue.  The slab's descriptor ends at row m: rows beyond it are dropped by the bounds check.
+__device__ __forceinline__ void w3_partial_row(const GemmP& p, const f32x16_t (&acc)[5], char* ebuf, int mb, int ncol0, int lane, int split,
+                                               const f32x16_t (&give)[5], char* xbuf, const char* pbuf) {
+  const int l31 = lane & 31, hi = lane >> 5;
+  const __amdgpu_buffer_rsrc_t r_ws = make_rsrc(p.ws + (long)split * p.m * p.n, (unsigned)((long)p.m * p.n * 4));
+  auto strip_off = [](int row, int quad, int nq) { return row * 256 + ((quad ^ (row & (nq - 1))) << 4); };
+#pragma unroll
+  for (int jc = 0; jc < 5; jc += 2) {
+    const int nfr = (jc + 1 < 5) ? 2 : 1;
+    const int q_per_row = nfr * 8, rows_per_pass = 64 / q_per_row;
+    const int qq = lane % q_per_row, rq = lane / q_per_row;
+    const int gn = ncol0 + jc * 32 + qq * 4;
+    if (jc) __syncthreads();                                 // the partner has consumed the previous chunk's exchange buffer
+#pragma unroll
+    for (int jj = 0; jj < 2; ++jj)
+      if (jc + jj < 5) {
+#pragma unroll
+        for (int g = 0; g < 4; ++g)
+          *(float4*)(xbuf + ((jj * 4 + g) * 64 + lane) * 16) =
+              make_float4(give[jc + jj][g * 4], give[jc + jj][g * 4 + 1], give[jc + jj][g * 4 + 2], give[jc + jj][g * 4 + 3]);
+      }
+    __syncthreads();
+#pragma unroll
+    for (int jj = 0; jj < 2; ++jj)
+      if (jc + jj < 5) {
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+          const float4 o = *(const float4*)(pbuf + ((jj * 4 + g) * 64 + lane) * 16);
+          *(float4*)(ebuf + strip_off(l31, jj * 8 + 2 * g + hi, nfr * 8)) =
+              make_float4(acc[jc + jj][g * 4] + o.x, acc[jc + jj][g * 4 + 1] + o.y, acc[jc + jj][g * 4 + 2] + o.z, acc[jc + jj][g * 4 + 3] + o.w);
+        }
+      }
+    const unsigned o_ws = ((unsigned)(mb + rq) * (unsigned)p.n + (unsigned)gn) * 4u, s_ws = (unsigned)(rows_per_pass * p.n * 4);
+#pragma unroll
+    for (int pass = 0; pass < 8; ++pass)
+      if (pass * rows_per_pass < 32)
+        st128f(r_ws, (int)(o_ws + pass * s_ws), *(const float4*)(ebuf + strip_off(pass * rows_per_pass + rq, qq, q_per_row)));
+  }
+}
+
 template <typename Tag, int MODE, int LNROWS>
 __global__ __launch_bounds__(512, 2) void gemm_w320_kernel(const GemmP p) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -441,9 +484,14 @@ __global__ __launch_bounds__(512, 2) void gemm_w320h_kernel(const GemmP p) {
     const int nwg = gridDim.x, q = nwg >> 3, r = nwg & 7, xcd = bid & 7, idx = bid >> 3;
     bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
   }
+  // split-K (p.splitk > 1): the K slices of one tile sit next to each other in the launch order; slice `split` covers slabs
+  // [kt_lo, kt_lo + S) of the (tap, source, k) walk and ends in w3_partial_row instead of the epilogue
+  int split = 0;
+  if (p.splitk > 1) { split = bid % p.splitk; bid /= p.splitk; }
   const int tile_m = bid / p.tiles_n, tile_n = bid - tile_m * p.tiles_n;
   const int m0 = tile_m * BM, n0 = tile_n * BN;
-  const int S = p.kt_total;
+  const int kt_lo = p.splitk > 1 ? (int)((long)p.kt_total * split / p.splitk) : 0;
+  const int S = p.splitk > 1 ? (int)((long)p.kt_total * (split + 1) / p.splitk) - kt_lo : p.kt_total;
 
   const __amdgpu_buffer_rsrc_t ra0 = make_rsrc(p.a0, p.a0_bytes);
   const __amdgpu_buffer_rsrc_t ra1 = make_rsrc(p.a1 ? p.a1 : p.a0, p.a1_bytes);
@@ -466,6 +514,12 @@ __global__ __launch_bounds__(512, 2) void gemm_w320h_kernel(const GemmP p) {
     }
   }
   int p_tap = 0, p_src = 0, p_kc = 0, p_slab = 0;
+  if (kt_lo) {                                               // the walk starts inside the K range: (tap, source, k step) of slab kt_lo
+    const int per_tap = p.nk0 + p.nk1;
+    p_tap = kt_lo / per_tap;
+    p_kc = kt_lo - p_tap * per_tap;
+    if (p_kc >= p.nk0) { p_src = 1; p_kc -= p.nk0; }
+  }
   auto refresh = [&]() {
     const long lda = p_src ? p.lda1 : p.lda0;
 #pragma unroll
@@ -486,7 +540,8 @@ __global__ __launch_bounds__(512, 2) void gemm_w320h_kernel(const GemmP p) {
     }
   };
   refresh();
-  int p_soff_a = 0, p_soff_w = 0;
+  int p_soff_a = __builtin_amdgcn_readfirstlane(p_kc * 64 * ES);
+  int p_soff_w = __builtin_amdgcn_readfirstlane((int)(((long)p_tap * (p.k0 + p.k1) + (p_src ? p.k0 : 0) + p_kc * 64) * ES));
   bool p_ok = S > 0;
   auto advance = [&]() {
     if (++p_kc == (p_src ? p.nk1 : p.nk0)) {
@@ -653,6 +708,11 @@ __global__ __launch_bounds__(512, 2) void gemm_w320h_kernel(const GemmP p) {
   char* xbuf = smem + 65536 + wid * 8192;
   const char* pbuf = smem + 65536 + (wid ^ 4) * 8192;
   const int mb = m0 + wr * 64, ncol0 = n0 + wc * 160;
+  if (p.splitk > 1) {
+    if (grp == 0) w3_partial_row(p, acc[0], ebuf, mb, ncol0, lane, split, acc[1], xbuf, pbuf);
+    else w3_partial_row(p, acc[1], ebuf, mb + 32, ncol0, lane, split, acc[0], xbuf, pbuf);
+    return;
+  }
   if (grp == 0) w3_epilogue_dispatch<Tag, 1, true>(p, &acc[0], &rs[0], ebuf, mb, ncol0, lane, acc[1], xbuf, pbuf);
   else w3_epilogue_dispatch<Tag, 1, true>(p, &acc[1], &rs[1], ebuf, mb + 32, ncol0, lane, acc[0], xbuf, pbuf);
 }
@@ -685,7 +745,12 @@ static void launch_w320h_inst(GemmP& p, hipStream_t st) {
   static_assert(lds <= 160 * 1024 && 2 * 57344 <= lds && 16 * 8192 <= lds, "w320h LDS");
   static unsigned long long attr_done = 0;
   tt_lds_opt_in((const void*)gemm_w320h_kernel<Tag, MODE, LNROWS>, lds, &attr_done);
-  hipLaunchKernelGGL((gemm_w320h_kernel<Tag, MODE, LNROWS>), dim3(p.tiles_m * p.tiles_n), dim3(512), lds, st, p);
+  hipLaunchKernelGGL((gemm_w320h_kernel<Tag, MODE, LNROWS>), dim3(p.tiles_m * p.tiles_n * p.splitk), dim3(512), lds, st, p);
+  if (p.splitk > 1) {                                        // second pass: the slabs summed in a fixed order + the full epilogue
+    long blocks = ((long)p.m * (p.n >> 2) + 255) / 256;
+    if (blocks > 2048) blocks = 2048;
+    hipLaunchKernelGGL(splitk_epilogue_kernel<Tag>, dim3((unsigned)blocks), dim3(256), 0, st, p);
+  }
 }
 template <typename Tag>
 static void launch_w320h_tag(GemmP& p, hipStream_t st) {
