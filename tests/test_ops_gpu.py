@@ -750,7 +750,7 @@ def test_errors_are_loud(ops):
         ops.gemm(torch.zeros(8, 16, dtype=torch.float16), torch.zeros(8, 16, dtype=torch.float16))
 
 
-@pytest.mark.parametrize("cfg", list(range(20)))
+@pytest.mark.parametrize("cfg", list(range(21)))
 def test_gemm_every_tile_configuration(ops, cfg):
     """each entry of the tile table in gemm.hip, forced, on a ragged linear and a 2-source conv (bf16)."""
     from this_and_that_vdm_amd import _lib
@@ -842,7 +842,7 @@ def test_gemm_tall_short_k(ops, n, rowvec):
 
 
 @pytest.mark.parametrize("m,n,k,cfg", [(12544, 640, 640, -1), (3136, 1280, 1280, -1), (12544, 2560, 320, -1), (50176, 320, 320, -1),
-                                       (3136, 1280, 640, 1), (1500, 640, 1280, 2), (8192, 1024, 512, 13), (4096, 640, 512, 14)])
+                                       (3136, 1280, 640, 1), (1500, 640, 1280, 2), (8192, 1024, 512, 13), (4096, 640, 512, 14), (3136, 1280, 5120, 20), (3000, 1280, 1344, 20)])
 def test_gemm_is_repeatable_under_load(ops, m, n, k, cfg):
     """the K loop reads LDS with instructions the compiler cannot see and orders them against the LDS-DMA by counted
     waits and barriers only: a misplaced wait would show up as run-to-run differences.  40 launches back to back

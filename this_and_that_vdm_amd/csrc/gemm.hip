@@ -56,6 +56,7 @@ constexpr TileCfg kCfgs[] = {        // keep in step with launch<Tag>() in gemm_
   {256, 256, 32, 4, 2, 4},   // 17: 8 waves, wave tile 128x64, 128 KiB: three 32 KiB tiles in flight
   {256, 128, 64, 2, 4, 2},   // 18: 8 waves, wave tile 64x64, 96 KiB, plain double buffer
   {256, 128, 32, 5, 4, 2},   // 19: 8 waves, wave tile 64x64, 120 KiB: four 24 KiB tiles in flight
+  {128, 128, 128, 2, 4, 2},  // 20: 8 waves, 128-deep K steps (256-byte rows), 128 KiB double buffer: half the barriers per MFMA (opt-in, see make_plan)
 };
 constexpr int kNumCfgs = sizeof(kCfgs) / sizeof(kCfgs[0]);
 
@@ -88,7 +89,7 @@ struct Plan { int cfg, splitk; };
 // `wide_ok`: the 256x128 tile pays for tall-and-wide problems (GEGLU projections, fused QKV) unless the epilogue reads
 // per-row tensors (residual / blend / row vector): its 128-VGPR budget has no room to preload them, so they would be read
 // between the stores (measured: 16 us epilogue instead of 3)
-Plan make_plan(int m, int n, long ktot, bool allow_split, bool wide_ok = true, bool mode0 = false) {
+Plan make_plan(int m, int n, long ktot, bool allow_split, bool wide_ok = true, bool mode0 = false, bool k128 = false) {
   Plan pl{0, 1};
   const int f = forced_cfg();
   const long b128 = (long)ceil_div(m, 128) * ceil_div(n, 128);
@@ -110,8 +111,12 @@ Plan make_plan(int m, int n, long ktot, bool allow_split, bool wide_ok = true, b
   if (deep < 0) { const char* e = getenv("TT_GEMM_DEEP"); deep = e ? atoi(e) : 1; }
   if (deep && f < 0 && b128 <= 256 && ktot > 0) {
     // at most one 128x128 tile per CU: LDS is free for a 4-deep ring (prefetch distance 3), which beats two resident
-    // blocks with a double buffer once the loads really overlap the MFMAs; K is split only as far as whole CUs are idle
-    pl.cfg = 16;
+    // blocks with a double buffer once the loads really overlap the MFMAs; K is split only as far as whole CUs are idle.
+    // (128-deep K steps for channel counts that are multiples of 128 -- cfg 20, one barrier pair per 16 MFMAs of a wave -- are faster
+    // in isolation: FF2 at 3136 rows 690 -> 791 TFLOP/s, K = 1280 509 -> 556, the 3x3 conv 792 -> 848 (tools/gemm_bench.py 16 20), and
+    // slower in the step: 31.19 / 31.23 -> 31.48 / 31.51 ms, restricted to K >= 4096 30.83 / 31.08 -> 31.26 / 31.17: a double buffer
+    // has one K step of prefetch where the 4-deep ring has three.  Opt-in: TT_GEMM_DEEP=2.)
+    pl.cfg = (deep == 2 && k128) ? 20 : 16;
     long s = allow_split ? 256 / b128 : 1;
     if (s > kt / 8) s = kt / 8;
     if (s > 16) s = 16;
@@ -260,7 +265,8 @@ static Plan plan_for(const TtGemmArgs* a) {
   if (a->dtype == TT_F32) return Plan{plan_f32(a->m, a->n), 1};
   const int taps = a->mode == 1 ? 9 : (a->mode == 2 ? 3 : 1);
   const bool allow = !a->geglu && !a->ln_fold && !a->out_fp8;       // a K slice would see only part of a LayerNorm row
-  Plan pl = make_plan(a->m, a->n, (long)taps * (a->k0 + a->k1), allow, !(a->residual || a->blend || a->rowvec), a->mode == 0);
+  const bool k128 = (a->k0 & 127) == 0 && (a->k1 & 127) == 0;
+  Plan pl = make_plan(a->m, a->n, (long)taps * (a->k0 + a->k1), allow, !(a->residual || a->blend || a->rowvec), a->mode == 0, k128);
   if (a->ln_fold && !ln_capable(pl.cfg)) {           // a forced tile shape without the fused variant: planner's own choice
     const int keep = g_forced_cfg;
     g_forced_cfg = -1;

@@ -1079,7 +1079,8 @@ void launch(GemmP& p, int cfg, hipStream_t st) {          // cfg = index into kC
     case 16: launch_cfg<Tag, 128, 128, 64, 4, 4, 2, true>(p, st); break;
     case 17: launch_cfg<Tag, 256, 256, 32, 4, 2, 4>(p, st); break;
     case 18: launch_cfg<Tag, 256, 128, 64, 2, 4, 2>(p, st); break;
-    default: launch_cfg<Tag, 256, 128, 32, 5, 4, 2>(p, st); break;
+    case 19: launch_cfg<Tag, 256, 128, 32, 5, 4, 2>(p, st); break;
+    default: launch_cfg<Tag, 128, 128, 128, 2, 4, 2>(p, st); break;
   }
 }
 
