@@ -311,3 +311,33 @@ def test_split_k_default_route_is_the_third_level_conv(ops):
     assert name_of(z(3136, 1280), z(1280, 9 * 1280), mode=1, conv=(28, 8, 14, 8, 14, 1, 0)).startswith("gemm_w320h_kernel<")
     assert not name_of(z(3136, 5120), z(1280, 5120)).startswith("gemm_w320")
     assert not name_of(z(784, 1280), z(1280, 9 * 1280), mode=1, conv=(28, 4, 7, 4, 7, 1, 0)).startswith("gemm_w320")
+
+
+def test_split_k_without_workspace_falls_back_to_the_tiled_plan(ops, monkeypatch):
+    """a caller of the C ABI that passes no workspace (ws = NULL) gets the un-split tiled plan, same result."""
+    from this_and_that_vdm_amd.packing import pack_conv3x3
+    dtype = torch.bfloat16
+    nimg, h, w, c, cout = 28, 8, 14, 320, 1280
+    x = rnd(nimg, c, h, w, dtype=dtype, seed=1)
+    wt = rnd(cout, c, 3, 3, dtype=dtype, seed=3, scale=(9 * c) ** -0.5)
+    tok = x.permute(0, 2, 3, 1).reshape(-1, c).contiguous().cuda()
+    wp = pack_conv3x3(wt).cuda()
+    kw = dict(mode=1, conv=(nimg, h, w, h, w, 1, 0))
+
+    def run():
+        ops.PROFILE = []
+        o = ops.gemm(tok, wp, **kw)
+        torch.cuda.synchronize()
+        n = ops.PROFILE[0][0]
+        ops.PROFILE = None
+        return o, n
+
+    split, name = run()
+    assert name.startswith("gemm_w320h_kernel<"), name
+    lib = ops._lib.load()
+    monkeypatch.setattr(lib, "tt_gemm_ws_bytes", lambda g: 0)
+    plain, name = run()
+    assert name.startswith("gemm_kernel<"), name
+    ref = F.conv2d(x.float(), wt.float(), None, padding=1).permute(0, 2, 3, 1).reshape(-1, cout)
+    close(split, ref, dtype, scale=2.0)
+    close(plain, ref, dtype, scale=2.0)
