@@ -2,7 +2,7 @@
 """denoise-steps/sec of the SVD denoise hot path (GestureNet ControlNet + spatio-temporal UNet + CFG + Euler),
 BASELINE.json's metric, on N MI355X GPUs of one node.
 
-    python bench.py [--gpus N] [--steps K] [--warmup W] [--mode vgl|vl] [--res lo|hi] [--dtype bf16|fp16]
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--mode vgl|vl] [--res lo|ref|hi] [--dtype bf16|fp16]
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
 
 One "step" = one iteration of the reference loop body
@@ -27,10 +27,18 @@ sys.path.insert(0, REPO)
 # algorithmic TFLOP per denoise step (2*MAC for conv/Linear/QK^T/PV, context K/V counted once per batch element):
 # BASELINE.md section 2 / SURVEY.md 8(d)
 STEP_TFLOP = {("vgl", "lo"): 20.10, ("vl", "lo"): 14.77, ("vgl", "hi"): 91.32, ("vl", "hi"): 66.89}
-LATENT = {"lo": (32, 56), "hi": (64, 112)}
+# "ref" = the reference's own default resolution, 256x384 (config/train_image2video_gesturenet.yaml:18-19, test_code/inference.py:135-136):
+# 32x48 latents.  Its algorithmic TFLOP follow from the two figures above: per step  a * hw + b * hw^2  (everything is linear in the
+# token count hw except the spatial self-attention, at every level), fitted through hw = 1792 (lo) and 7168 (hi):
+# VGL a * 1792 = 19.19, b * 1792^2 = 0.91;  VL 14.119, 0.651;  hw = 1536 gives 17.12 / 12.58 (bench.py's own launch count at that size:
+# `executed_tflop_per_step` in the line).
+STEP_TFLOP[("vgl", "ref")] = 19.19 * (1536 / 1792) + 0.91 * (1536 / 1792) ** 2
+STEP_TFLOP[("vl", "ref")] = 14.119 * (1536 / 1792) + 0.651 * (1536 / 1792) ** 2
+LATENT = {"lo": (32, 56), "ref": (32, 48), "hi": (64, 112)}
 PEAK_TFLOPS = 2500.0          # dense bf16/fp16 MFMA peak, MI355X_MICROARCH.md (spec ~2.5 PF; 2495 measured)
 PEAK_TFLOPS_F32 = 157.3       # f32-input MFMA (v_mfma_f32_32x32x2_f32): the fp32 vector rate, same guide
 FRAMES, CTX_TOKENS, CTX_DIM, STEPS_PER_REQUEST = 14, 78, 1024, 25
+TRAFFIC_FILE = "r5_hbm_traffic.json"     # written by tools/profile_round.sh (rocprofv3 --pmc passes), stamped with the kernel-source hash
 
 
 def csrc_hash() -> str:
@@ -96,9 +104,12 @@ def make_loop(unet, cn, res, device, seed):
     return loop, args
 
 
-def advance(loop, args, n):
-    for _ in range(n):
-        if loop.step_index == loop.num_steps:       # next request (same shapes -> same captured graph)
+def advance(loop, args, n, fresh=False):
+    """n steps; a request that has run out of steps is followed by the next one (same shapes -> same captured graph).
+    fresh: start with a NEW request whatever the loop's position -- the timed window opens with a begin(), so the per-request
+    set-up (context K/V projections, FiLM table of all steps) is inside it for every --steps / --warmup combination."""
+    for i in range(n):
+        if loop.step_index == loop.num_steps or (fresh and i == 0):
             loop.begin(**args)
         loop.step()
 
@@ -298,7 +309,8 @@ def main():
     ap.add_argument("--steps", type=int, default=25)
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--mode", choices=["vgl", "vl"], default="vgl")
-    ap.add_argument("--res", choices=["lo", "hi"], default="lo")
+    ap.add_argument("--res", choices=["lo", "ref", "hi"], default="lo",
+                    help="lo 256x448 (BASELINE's headline), ref 256x384 (the reference's own default, config/train_image2video_gesturenet.yaml), hi 512x896")
     ap.add_argument("--dtype", choices=["bf16", "fp16", "f32"], default="bf16",
                     help="f32 = TT_F32 reference-precision mode (exact-fp32 MFMA, 1/16 of the bf16 rate): the price of meeting rtol 1e-3 / atol 1e-4")
     ap.add_argument("--block", choices=["l0hi"], default=None,
@@ -370,9 +382,13 @@ def main():
     advance(loop, args, a.warmup)
     fence()
     t0 = time.perf_counter()
-    advance(loop, args, a.steps)
+    advance(loop, args, a.steps, fresh=True)        # >= one begin() per 25 steps inside the timed region
     fence()
     dt = time.perf_counter() - t0
+    tb = time.perf_counter()                        # what one request set-up costs on its own (reported, already inside dt above)
+    loop.begin(**args)
+    torch.cuda.synchronize()
+    begin_ms = (time.perf_counter() - tb) * 1e3
     from this_and_that_vdm_amd.dist import max_over_ranks
     gdev = "cpu" if one_gpu else device
     allv = gather_floats([dt / a.steps * 1e3, float(checksum % (1 << 52)), getattr(build_models, "prepare_s", 0.0), bcast_s or 0.0], gdev)
@@ -391,16 +407,16 @@ def main():
         # stamped with where it was measured; it is null (not a stale number) when the dominant kernel has no entry there.
         # It is reported only when that profile was taken on THIS binary (same hash of the kernel sources); otherwise null.
         traffic, traffic_src = None, None
-        tfile = os.path.join(REPO, "profiles", "r4_hbm_traffic.json")
+        tfile = os.path.join(REPO, "profiles", TRAFFIC_FILE)
         if os.path.exists(tfile):
             doc = json.load(open(tfile))
             if doc.get("_kernel_source_sha16") == csrc_hash():
                 traffic = doc.get(f"{a.mode}_{a.res}", {}).get(name.replace("ttg::", ""))
                 if traffic is not None:
-                    traffic_src = ("profiles/r4_hbm_traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of tools/pmc_step.py on the "
+                    traffic_src = (f"profiles/{TRAFFIC_FILE} (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of tools/pmc_step.py on the "
                                    f"same kernel sources, sha16 {doc.get('_kernel_source_sha16')})")
             else:
-                traffic_src = ("null: profiles/r4_hbm_traffic.json was measured on other kernel sources "
+                traffic_src = (f"null: profiles/{TRAFFIC_FILE} was measured on other kernel sources "
                                f"({doc.get('_kernel_source_sha16')} != {csrc_hash()}); re-run tools/profile_round.sh")
         roofline = {"bound": "mfma", "kernel": name, "launches_per_step": cnt,
                     "achieved": fl / sec / 1e12, "peak": peak, "unit": "TFLOP/s",
@@ -428,7 +444,8 @@ def main():
                                    f"{CTX_TOKENS} context tokens, heads (5,10,20,20)",
                        "mode": a.mode, "latent": [FRAMES, 4, h, w], "requests_per_gpu": 1,
                        "parallelism": f"{world} independent request(s), one per GPU; RCCL weight broadcast at start-up only",
-                       "hipgraph": True, "finite_output": finite, "spatial_self_attention": a.attn,
+                       "hipgraph": True, "finite_output": finite, "begin_ms_per_request": begin_ms,
+                       "begins_in_timed_region": (a.steps + STEPS_PER_REQUEST - 1) // STEPS_PER_REQUEST, "spatial_self_attention": a.attn,
                        "step_tflop_algorithmic": step_tflop,
                        "step_mfma_frac_of_peak": step_tflop / (ms * 1e-3) / peak,
                        "weight_broadcast_s": max(per_rank_bcast_s) if world > 1 else None, "rendezvous_s": rendezvous_s if world > 1 else None,

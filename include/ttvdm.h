@@ -187,7 +187,8 @@ typedef struct TtAttnArgs {
    * states (rows addressed like q: query r of sequence s is row s*lq + r), qc = the LayerNorm width = columns of wq.
    * wq [heads*64, ldwq] and bq [heads*64] are the LayerNorm-folded projection (packing.fold_layernorm) with bits 2 and 3 of the
    * row index swapped inside every group of 16 rows (packing.permute_q_rows): the projection's MFMA accumulators then ARE the
-   * Q^T operand fragments of the score product. */
+   * Q^T operand fragments of the score product.  qx and wq hold elements of `dtype`, bq is fp32; all three start on 16-byte
+   * boundaries (TT_EINVAL otherwise), wq spans heads*64 rows of qc elements. */
   const void* qx; int64_t ldqx;
   const void* wq; int64_t ldwq;
   const float* bq;

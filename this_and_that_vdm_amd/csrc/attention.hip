@@ -912,6 +912,9 @@ extern "C" int tt_attention(const TtAttnArgs* a, tt_stream_t stream) {
       TT_FAIL(TT_EUNSUPPORTED, "tt_attention: the fused query projection serves cross-attention (mask 1 / 2), head_dim 64, 16-bit storage");
     if (!a->wq || !a->bq || a->qc < 64 || (a->qc & 63) || (a->ldqx & 7) || (a->ldwq & 7) || !(a->ln_eps > 0.f))
       TT_FAIL(TT_EINVAL, "tt_attention: fused query projection needs wq, bq, qc %% 64 == 0, row strides %% 8 == 0, ln_eps > 0");
+    // the kernel reads bq as float4 and x / wq rows as 16-byte chunks through buffer descriptors
+    if ((((size_t)a->qx | (size_t)a->wq | (size_t)a->bq)) & 15)
+      TT_FAIL(TT_EINVAL, "tt_attention: fused query projection needs qx, wq and bq on 16-byte boundaries");
   }
   if (a->head_dim != 64 && a->head_dim != 128) TT_FAIL(TT_EUNSUPPORTED, "tt_attention: head_dim %d (64 or 128)", a->head_dim);
   if (a->nseq <= 0 || a->lq <= 0 || a->heads <= 0 || a->lk <= 0) TT_FAIL(TT_EINVAL, "tt_attention: empty problem");

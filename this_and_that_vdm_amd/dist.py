@@ -33,8 +33,11 @@ def init_ranks(backend: str, rank: int, world: int, local_rank: int, device=None
                                   f"(HIP_VISIBLE_DEVICES={os.environ.get('HIP_VISIBLE_DEVICES')!r}, "
                                   f"ROCR_VISIBLE_DEVICES={os.environ.get('ROCR_VISIBLE_DEVICES')!r}); one rank per GPU is required")
         if os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0") != "0":
-            raise RendezvousError("HSA_ENABLE_IPC_MODE_LEGACY must be 0 for RCCL on this host (dmabuf IPC only); "
-                                  f"found {os.environ['HSA_ENABLE_IPC_MODE_LEGACY']!r}")
+            # a property of the host driver this was developed on (dmabuf IPC only), not of the library: warn, do not refuse --
+            # if the setting really is wrong for the host, the probe collectives below fail with the transport's own message
+            import warnings
+            warnings.warn("HSA_ENABLE_IPC_MODE_LEGACY=" + repr(os.environ["HSA_ENABLE_IPC_MODE_LEGACY"]) + ": hosts whose driver only "
+                          "supports dmabuf IPC need 0 for RCCL (hipIpcGetMemHandle fails otherwise)", RuntimeWarning, stacklevel=2)
     for var in ("MASTER_ADDR", "MASTER_PORT"):
         if world > 1 and not os.environ.get(var):
             raise RendezvousError(f"{var} is not set: launch with torch.distributed.run --master-addr 127.0.0.1 --master-port P")
@@ -60,10 +63,22 @@ def init_ranks(backend: str, rank: int, world: int, local_rank: int, device=None
             raise RendezvousError(f"first collective returned wrong data on rank {rank}: broadcast {float(probe.item())} "
                                   f"(expected 1.0), all-reduce {float(ones.item())} (expected {world})")
     except RendezvousError:
+        _drop_group()
         raise
     except Exception as e:                                   # noqa: BLE001
+        _drop_group()
         raise RendezvousError(f"first collective over {backend!r} failed on rank {rank}/{world}: {type(e).__name__}: {e}") from e
     return time.perf_counter() - t0
+
+
+def _drop_group() -> None:
+    """A failed probe must not leave a half-working process group behind: a caller that catches RendezvousError and retries (or
+    the next test) would find dist.is_initialized() True."""
+    try:
+        if dist.is_initialized():
+            dist.destroy_process_group()
+    except Exception:                                        # noqa: BLE001 -- the original failure is what gets reported
+        pass
 
 
 def gather_floats(values, device) -> list:

@@ -212,6 +212,11 @@ def attention(q, k, vt, out, *, nseq, lq, heads, head_dim, mask, lk, k_seq_strid
     lib = _lib.load()
     a = TtAttnArgs()
     if qx is not None:
+        # what the C entry point cannot see through raw pointers: element types and the weight's extent (heads * 64 rows of qc)
+        if wq.dtype != qx.dtype or bq.dtype != torch.float32 or not bq.is_contiguous() or wq.stride(1) != 1 or \
+                tuple(wq.shape) != (heads * head_dim, qx.shape[1]) or bq.numel() != heads * head_dim:
+            raise RuntimeError(f"attention: fused query projection needs wq [{heads * head_dim}, {qx.shape[1]}] in {qx.dtype} and a contiguous "
+                               f"fp32 bq [{heads * head_dim}]; got wq {tuple(wq.shape)} {wq.dtype}, bq {tuple(bq.shape)} {bq.dtype}")
         a.qx, a.ldqx, a.wq, a.ldwq, a.bq, a.qc, a.ln_eps = _p(qx), qx.stride(0), _p(wq), wq.stride(0), _p(bq), qx.shape[1], float(ln_eps)
         q = qx                                     # dtype / profiling below; a.q stays NULL
     else:

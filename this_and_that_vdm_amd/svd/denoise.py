@@ -68,12 +68,12 @@ class DenoiseLoop:
             self.controlnet.prepare()
         # a captured graph holds raw pointers into the models' packed weights: the pack generation of both models is part
         # of the key, so load_state_dict / .to() / in-place updates between requests drop the stale graphs
-        packs = (id(self.unet), self.unet._pack_gen, bool(self.unet.attention_fp8)) + \
-                ((id(self.controlnet), self.controlnet._pack_gen, bool(self.controlnet.attention_fp8)) if self.controlnet is not None else ())
+        packs = self._pack_state()
         key = (b, f, h, w, dtype, self.controlnet is not None, tuple(encoder_hidden_states.shape), len(timesteps),
                guidance_scale is not None, self.image_guidance_scale, packs)   # the image scale is baked into the graph
         if key != self._key:                    # new shapes or new weights: new static buffers, new graph
             self._graph, self._graph_off, self._key, self._static = None, None, key, {}
+        self._packs = packs                     # what the FiLM table, the context projections and the graphs below were built from
         self.geom, self.dtype = Geom(b, f, h, w), dtype
         f32 = lambda t: t.to(device=dev, dtype=torch.float32).contiguous()
         sig = f32(sigmas)
@@ -122,6 +122,21 @@ class DenoiseLoop:
             raise ValueError("controlnet_keep needs one 0.0/1.0 entry per step")
         self.step_index = 0
         return self
+
+    def _pack_state(self, repack: bool = True):
+        """(identity, pack generation, fp8 switch) of both models: prepare() bumps the generation on every repack.
+        repack=True (begin): prepare() first, so parameters that changed since the last pack are re-packed now.
+        repack=False (step): nothing is packed; a model whose parameters no longer match its pack (in-place update, .to(),
+        load_state_dict, invalidate_packs) reports generation -1, which never equals what begin() recorded."""
+        st = ()
+        for m in (self.unet, self.controlnet):
+            if m is None:
+                continue
+            if repack:
+                m.prepare()
+            fresh = repack or getattr(m, "_packed_key", None) == m._pack_key()
+            st += (id(m), m._pack_gen if fresh else -1, bool(m.attention_fp8))
+        return st
 
     def _static_set(self, name: str, value: torch.Tensor) -> torch.Tensor:
         cur = self._static.get(name)
@@ -205,6 +220,11 @@ class DenoiseLoop:
         """Advance the latents by one Euler step (asynchronous; call torch.cuda.synchronize() to wait)."""
         if self.step_index >= self.num_steps:
             raise RuntimeError("denoise loop already finished; call begin() for a new request")
+        # begin() evaluated the FiLM rows of ALL steps and the context K/V from the weights of that moment, and the captured graph
+        # holds pointers into that pack: a weight reload / repack between begin() and step() must not be served from them
+        if self._pack_state(repack=False) != self._packs:
+            raise RuntimeError("model weights were re-packed (load_state_dict / .to() / in-place update) after DenoiseLoop.begin(): "
+                               "call begin() again -- the per-request FiLM table and context projections belong to the old weights")
         self.cur.copy_(self.table[self.step_index])
         use_cn = self.controlnet is not None and self.keep[self.step_index] != 0.0
         if self.film_cur_u is not None:

@@ -128,7 +128,8 @@ class _Side:
     def _event():
         ev = torch.cuda.Event()
         _Side._events.append(ev)
-        if len(_Side._events) > 8192:
+        # trim the ring only OUTSIDE a capture: the oldest entries may have been recorded by the capture that is still open
+        if len(_Side._events) > 8192 and not torch.cuda.is_current_stream_capturing():
             del _Side._events[:4096]
         return ev
 
@@ -481,16 +482,40 @@ def _self_attention(x, attn: Attention, wqk, bqk, wv, eps, g: Geom, ctx: StepCon
                          mask=0, lk=g.hw, k_seq_stride=g.hw, v_seq_stride=hwp)
 
 
-def _cross_attention(x, attn: Attention, wq, bq, eps, kv, g: Geom, ctx: StepContext, temporal: bool, fused=None):
-    """cross-attention on the UN-normalised hidden states (norm2 folded into the query projection).  ``fused`` = (wq, bq) with the
-    rows permuted for the attention kernel's own query projection (packing.permute_q_rows): no Q tensor, no projection launch."""
+class _QProj:
+    """The LayerNorm-folded query projection of a cross-attention layer, kept ONCE: row-permuted for the attention kernel's own
+    projection (packing.permute_q_rows) when that path can serve the layer (d = 64, 16-bit storage, TT_ATTN_QPROJ != 0), in the
+    plain order otherwise.  The other order is derived on demand (the permutation is an involution) -- e.g. for a row view whose
+    stride the fused path does not take -- so the default path does not hold a second copy of every to_q (~60 MB over both models)."""
+
+    def __init__(self, w: torch.Tensor, b: torch.Tensor, dim_head: int):
+        self.is_fused = ops.ATTN_QPROJ and dim_head == 64 and w.dtype in (torch.float16, torch.bfloat16)
+        self.w, self.b = (permute_q_rows(w), permute_q_rows(b.contiguous())) if self.is_fused else (w, b.contiguous())
+        self._other = None
+
+    def fused(self):
+        return (self.w, self.b) if self.is_fused else None
+
+    def plain(self):
+        if not self.is_fused:
+            return self.w, self.b
+        if self._other is None:
+            self._other = (permute_q_rows(self.w), permute_q_rows(self.b))
+        return self._other
+
+
+def _cross_attention(x, attn: Attention, qp: _QProj, eps, kv, g: Geom, ctx: StepContext, temporal: bool):
+    """cross-attention on the UN-normalised hidden states (norm2 folded into the query projection ``qp``).  With the row-permuted
+    weights (qp.fused()) the attention kernel projects the queries itself: no Q tensor, no projection launch."""
     off, c = kv
     mask = 2 if temporal else 1
     out = torch.empty((g.m, c), dtype=x.dtype, device=x.device)
     kw = dict(nseq=g.n, lq=g.hw, heads=attn.heads, head_dim=attn.dim_head, mask=mask, lk=ctx.s_ctx, k_seq_stride=ctx.s_pad,
               v_seq_stride=ctx.s_pad, frames=g.frames, ctx_batches=g.ctx_batches, batch0=g.batch0)
+    fused = qp.fused()
     if fused is not None and ops.attention_qproj_supported(x, attn.dim_head, mask):
         return ops.attention(None, ctx.k_all[:, off:off + c], ctx.vt_all[off:off + c], out, qx=x, wq=fused[0], bq=fused[1], ln_eps=eps, **kw)
+    wq, bq = qp.plain()
     q = ops.gemm(x, wq, bias=bq, ln_fold=1, ln_eps=eps)
     return ops.attention(q, ctx.k_all[:, off:off + c], ctx.vt_all[off:off + c], out, **kw)
 
@@ -522,9 +547,8 @@ class BasicTransformerBlock(_Packable):
         self.wv = zr(wv)
         self.wo1 = cv(self.attn1.to_out[0].weight)
         self.bo1 = (_f32(self.attn1.to_out[0].bias) + self.wo1.float() @ bv).contiguous()
-        wq2, self.bq2 = fold_layernorm(self.attn2.to_q.weight, None, n2.weight, n2.bias)
-        self.wq2 = zr(wq2)
-        self.q2_fused = (permute_q_rows(self.wq2), permute_q_rows(self.bq2.contiguous())) if self.attn2.dim_head == 64 else None
+        wq2, bq2 = fold_layernorm(self.attn2.to_q.weight, None, n2.weight, n2.bias)
+        self.q2 = _QProj(zr(wq2), bq2, self.attn2.dim_head)
         self.wo2, self.bo2 = cv(self.attn2.to_out[0].weight), _f32(self.attn2.to_out[0].bias)
         self.kv = reg.add_kv(self.attn2.to_k, self.attn2.to_v)
         self.ff.pack(reg, dtype, norm=self.norm3)
@@ -551,7 +575,7 @@ class BasicTransformerBlock(_Packable):
         live = ctx.live_batches(g)
         if live is None:
             x = ops.gemm(a, self.wo1, bias=self.bo1, residual=x)
-            a = _cross_attention(x, self.attn2, self.wq2, self.bq2, self.norm2.eps, self.kv, g, ctx, temporal=False, fused=self.q2_fused)
+            a = _cross_attention(x, self.attn2, self.q2, self.norm2.eps, self.kv, g, ctx, temporal=False)
             x = ops.gemm(a, self.wo2, bias=self.bo2, residual=x)
             return self.ff(x, residual=x, **ff_rv)
         # Batch elements with an all-zero context (the CFG uncond half): K = V = 0, so their cross-attention output is exactly 0
@@ -564,7 +588,7 @@ class BasicTransformerBlock(_Packable):
             rows = g.frames * g.hw
             xs = x[first * rows:(first + count) * rows]
             gl = Geom(count, g.frames, g.h, g.w, g.batch0 + first, g.ctx_batches)
-            a = _cross_attention(xs, self.attn2, self.wq2, self.bq2, self.norm2.eps, self.kv, gl, ctx, temporal=False, fused=self.q2_fused)
+            a = _cross_attention(xs, self.attn2, self.q2, self.norm2.eps, self.kv, gl, ctx, temporal=False)
             ops.gemm(a, self.wo2, bias=self.bo2, residual=xs, out=xs)
         return self.ff(x, residual=x, **ff_rv)
 
@@ -597,9 +621,8 @@ class TemporalBasicTransformerBlock(_Packable):
         self.wqkv = zr(torch.cat([w for w, _ in folded], 0))
         self.bqkv = torch.cat([b for _, b in folded], 0).contiguous()
         self.wo1, self.bo1 = cv(self.attn1.to_out[0].weight), _f32(self.attn1.to_out[0].bias)
-        wq2, self.bq2 = fold_layernorm(self.attn2.to_q.weight, None, n2.weight, n2.bias)
-        self.wq2 = zr(wq2)
-        self.q2_fused = (permute_q_rows(self.wq2), permute_q_rows(self.bq2.contiguous())) if self.attn2.dim_head == 64 else None
+        wq2, bq2 = fold_layernorm(self.attn2.to_q.weight, None, n2.weight, n2.bias)
+        self.q2 = _QProj(zr(wq2), bq2, self.attn2.dim_head)
         self.wo2, self.bo2 = cv(self.attn2.to_out[0].weight), _f32(self.attn2.to_out[0].bias)
         self.bo12 = (self.bo1 + self.bo2).contiguous()      # rows whose cross-attention context is all zeros (forward)
         self.kv = reg.add_kv(self.attn2.to_k, self.attn2.to_v)
@@ -624,7 +647,7 @@ class TemporalBasicTransformerBlock(_Packable):
         live = ctx.live_classes(g)
         if live is None:
             t = ops.gemm(a, self.wo1, bias=self.bo1, residual=t)
-            a = _cross_attention(t, self.attn2, self.wq2, self.bq2, self.norm2.eps, self.kv, g, ctx, temporal=True, fused=self.q2_fused)
+            a = _cross_attention(t, self.attn2, self.q2, self.norm2.eps, self.kv, g, ctx, temporal=True)
             t = ops.gemm(a, self.wo2, bias=self.bo2, residual=t)
         else:
             # Rows of a residue class whose context is all zeros (the CFG uncond context: every other pixel, quirk Q3) get
@@ -651,11 +674,13 @@ class TemporalBasicTransformerBlock(_Packable):
                     akw = dict(nseq=g.n, lq=g.hw // cb, heads=self.attn2.heads, head_dim=self.attn2.dim_head, mask=1, lk=ctx.s_ctx,
                                k_seq_stride=ctx.s_pad, v_seq_stride=ctx.s_pad, frames=g.n, ctx_batches=cb, batch0=cls)
                     a = torch.empty((tv.shape[0], c), dtype=tv.dtype, device=tv.device)
-                    if self.q2_fused is not None and ops.attention_qproj_supported(tv, self.attn2.dim_head, 1):
-                        ops.attention(None, ctx.k_all[:, off:off + cc], ctx.vt_all[off:off + cc], a, qx=tv, wq=self.q2_fused[0],
-                                      bq=self.q2_fused[1], ln_eps=self.norm2.eps, **akw)
+                    fused = self.q2.fused()
+                    if fused is not None and ops.attention_qproj_supported(tv, self.attn2.dim_head, 1):
+                        ops.attention(None, ctx.k_all[:, off:off + cc], ctx.vt_all[off:off + cc], a, qx=tv, wq=fused[0],
+                                      bq=fused[1], ln_eps=self.norm2.eps, **akw)
                     else:
-                        q = ops.gemm(tv, self.wq2, bias=self.bq2, ln_fold=1, ln_eps=self.norm2.eps)
+                        wq2, bq2 = self.q2.plain()
+                        q = ops.gemm(tv, wq2, bias=bq2, ln_fold=1, ln_eps=self.norm2.eps)
                         ops.attention(q, ctx.k_all[:, off:off + cc], ctx.vt_all[off:off + cc], a, **akw)
                     ops.gemm(a, self.wo2, bias=self.bo2, residual=tv, out=tv)
             side.join()

@@ -44,3 +44,30 @@ def bench8(nseq, heads, L, d, iters=10):
 
 for args in ((28, 5, 1792, 64), (28, 5, 7168, 64), (28, 10, 1792, 64)):
     bench8(*args)
+
+
+def bench_cross(b, f, hw, heads, s=78, d=64, dtype=torch.bfloat16, iters=10):
+    """spatial cross-attention (mask 1) with the query projection fused in (TtAttnArgs.qx) at the model's live-row shapes:
+    14 frames of one batch element, 78 context tokens.  flops = scores + P V + the projection the kernel computes itself."""
+    from this_and_that_vdm_amd.packing import permute_q_rows
+    c = heads * d
+    sp = (s + 7) // 8 * 8
+    rows = b * f * hw
+    x = torch.randn(rows, c, device="cuda", dtype=dtype)
+    wq = permute_q_rows((torch.randn(c, c, device="cuda") * c ** -0.5).to(dtype)); bq = permute_q_rows(torch.randn(c, device="cuda"))
+    k = torch.randn(b * sp, c, device="cuda", dtype=dtype); vt = torch.randn(c, b * sp, device="cuda", dtype=dtype)
+    out = torch.empty(rows, c, device="cuda", dtype=dtype)
+    fn = lambda: ops.attention(None, k, vt, out, qx=x, wq=wq, bq=bq, ln_eps=1e-5, nseq=b * f, lq=hw, heads=heads, head_dim=d, mask=1, lk=s,
+                               k_seq_stride=sp, v_seq_stride=sp, frames=f, ctx_batches=b)
+    for _ in range(3): fn()
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(iters): fn()
+    e1.record(); torch.cuda.synchronize()
+    t = e0.elapsed_time(e1) / iters * 1e-3
+    fl = 4.0 * rows * heads * s * d + 2.0 * rows * c * c
+    print(f"cross+qproj rows {rows:6d} heads {heads:2d} C {c:4d} S {s}: {t*1e6:8.1f} us  {fl/t/1e12:7.1f} TFLOP/s  (x read + out write {2*rows*c*2/t/1e9:6.0f} GB/s)")
+
+for args in ((1, 14, 1792, 5), (1, 14, 448, 10), (1, 14, 112, 20), (1, 14, 7168, 5)):
+    bench_cross(*args)
