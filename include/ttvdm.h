@@ -57,7 +57,7 @@ const char* tt_last_error(void);
  * torch.cat([h, skip], dim=1) (unet_3d_blocks.py:2242,2352) without a concat buffer.
  * Epilogue, in this order (every term optional):
  *   acc *= 1/sigma of the LayerNorm-folded operand row (ln_fold, below)
- *   v = (acc + bias[n]) * acc_scale + rowvec[m / rowvec_rows][n]
+ *   v = (acc + bias[n]) * acc_scale + rowvec[m / rowvec_rows][n]        (row index taken modulo rowvec_mod when that is > 0)
  *   geglu: v = v_value * gelu_erf(v_gate)      (W rows pre-interleaved in 16-row groups: 8 value, 8 gate)
  *   v += residual[m][n];  v = alpha*blend[m][n] + (1-alpha)*v   (AlphaBlender, video branch)
  * `out` may alias `residual` (same pointer and stride: in-place update of the hidden states -- every element's residual is
@@ -95,6 +95,12 @@ typedef struct TtGemmArgs {
    * the Q | K and V^T operands of tt_attention's fp8 path (BASELINE config 5).  Plain mode-0 linears only (ln_fold and
    * out_col_hw are allowed; no geglu / residual / blend / rowvec / out_f32); dtype stays the 16-bit type of a0 / w. */
   int32_t out_fp8;
+  /* ABI 7.  rowvec_mod > 0: row m takes rowvec[(m / rowvec_rows) % rowvec_mod] -- a PERIODIC row vector.  rowvec_rows = 1,
+   * rowvec_mod = 2 gives even and odd rows their own vector: the temporal transformer block's output projection serves the rows of
+   * both context classes (quirk Q3 pairs query pixel p with context p mod 2; the class whose context is all zeros also receives the
+   * cross-attention's to_out bias, transformer_temporal.py:342-365 via TemporalBasicTransformerBlock) in ONE launch instead of one
+   * launch per class on strided row views.  0: the plain form above. */
+  int32_t rowvec_mod;
 } TtGemmArgs;
 int tt_gemm(const TtGemmArgs* args, tt_stream_t stream);
 /* which tile configuration tt_gemm will use for this problem: cfg[0..6] = BM, BN, BK, ring stages, waves along M,

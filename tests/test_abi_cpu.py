@@ -26,7 +26,7 @@ def test_header_and_binding_agree(lib):
 
 
 def test_version_and_arch(lib):
-    assert lib.tt_abi_version() == 6
+    assert lib.tt_abi_version() == 7
     assert lib.tt_target_arch() == b"gfx950"
 
 
@@ -83,7 +83,8 @@ def test_gemm_dispatch_rules_of_the_persistent_kernel(lib):
 
 def test_gemm_dispatch_rules_of_the_big_tile_kernel(lib):
     """tt_gemm_plan, host-only: which problems go to gemm_w320_kernel (reported as tile 256 x 320 x 64, stages 0, 4 x 2 waves):
-    16-bit problems with N = 320 t whose 256-row tiles fill >= 70 % of the CU x round slots -- Linear (also with the LayerNorm fold,
+    16-bit problems with N = 320 t whose 256-row tiles fill >= 60 % of the CU x round slots (TT_W320_MIN_FILL; 168 tiles at the
+    reference's default 256x384 qualify) -- Linear (also with the LayerNorm fold,
     two sources, residual / blend / row vector), conv3x3 stride 1, temporal conv; the knob tt_gemm_set_big_tile(0) turns it off."""
     import ctypes as C
     from this_and_that_vdm_amd import ops
@@ -109,6 +110,8 @@ def test_gemm_dispatch_rules_of_the_big_tile_kernel(lib):
     assert plan(200704, 320, 320)[0] == w320                                             # 64x112 latents: 784 tiles
     assert plan(50176, 320, 320, rowvec=16, rowvec_rows=1792, ld_rowvec=320)[0] == w320
     assert plan(50176, 320, 320, rowvec=16, rowvec_rows=16, ld_rowvec=320)[0] != w320     # row-vector groups shorter than a fragment row
+    assert plan(50176, 320, 320, rowvec=16, rowvec_rows=1, rowvec_mod=2, ld_rowvec=320)[0] == w320   # ... except the even / odd form (ABI 7)
+    assert plan(43008, 320, 320)[0] == w320                                              # 32x48 latents (256x384): 168 tiles, 66 %
     w320h = [128, 320, 64, 0, 2, 2, 1]
     l1conv = dict(k1=640, lda1=640, mode=1, nimg=28, hin=16, win=28, hout=16, wout=28, stride=1)
     assert plan(12544, 640, 640, **l1conv)[0] == w320h                                   # conv3x3 of the second level: 98 x 2 tiles of 128 rows

@@ -191,6 +191,62 @@ def test_full_size_two_steps_match_oracle(full, dtype, rel, cos):
 
 
 @torch.no_grad()
+def test_reference_default_resolution_256x384_matches_oracle(full):
+    """The reference's OWN default resolution: config/train_image2video_gesturenet.yaml:18-19 (height 256, width 384), run by
+    test_code/inference.py:135-136,254-255 -> 32x48 latents, 43 008 token rows (168 row tiles of 256: a different tile fill than
+    BASELINE's 32x56 on every GEMM route).  One full VGL step (GestureNet + UNet + CFG + Euler) on the fixture's weights:
+      TT_F32  the public forward() pair and the fused step, every element inside rtol 1e-3 / atol 1e-4;
+      fp16 / bf16  relative L2 of the network contribution to the latents at the 32x56 limits (4e-3 / 3e-2), graph == eager."""
+    from oracle.scheduler import EulerDiscreteScheduler as OSched
+    from this_and_that_vdm_amd.svd.denoise import DenoiseLoop
+    from this_and_that_vdm_amd.svd.scheduling_euler_discrete import EulerDiscreteScheduler
+    from this_and_that_vdm_amd.utils.synthetic import synthetic_inputs
+    h, w = 32, 48
+    inp = synthetic_inputs(2, FRAMES, h, w, CTX_TOKENS, CTX_DIM, seed=3)
+    osched = OSched()
+    osched.set_timesteps(25)
+    t = osched.timesteps[0]
+    x = torch.cat([osched.scale_model_input(torch.cat([inp["latents"]] * 2), t), inp["image_latents"]], dim=2)
+    down, mid = full["o_cn"](x, t, inp["encoder_hidden_states"], inp["added_time_ids"], controlnet_cond=torch.cat([inp["gesture_latents"]] * 2))
+    eps_ref = full["o_unet"](x, t, inp["encoder_hidden_states"], inp["added_time_ids"], down_block_additional_residuals=down,
+                             mid_block_additional_residual=mid)
+    u, c = eps_ref.chunk(2)
+    out = osched.step(u + inp["guidance_scale"] * (c - u), t, inp["latents"])
+    lat_ref = out[0] if isinstance(out, (tuple, list)) else getattr(out, "prev_sample", out)
+    # ---- TT_F32: forward pair + fused step, elementwise
+    unet, cn = _product(full, torch.float32)
+    dev = lambda v: v.cuda()
+    ehs, ati = dev(inp["encoder_hidden_states"]), dev(inp["added_time_ids"])
+    d32, m32 = cn(dev(x), float(t), ehs, ati, controlnet_cond=dev(torch.cat([inp["gesture_latents"]] * 2)), return_dict=False)
+    for i, (a, b) in enumerate(zip(d32, down)):
+        assert_north_star(a, b, f"256x384 GestureNet down residual {i}")
+    assert_north_star(m32, mid, "256x384 GestureNet mid residual")
+    eps = unet(dev(x), float(t), ehs, ati, down_block_additional_residuals=d32, mid_block_additional_residual=m32, return_dict=False)[0]
+    print("256x384 VGL UNet forward, TT_F32 vs fp32 oracle:", err_stats(eps, eps_ref))
+    assert_north_star(eps, eps_ref, "256x384 UNet forward (VGL)")
+    sched = EulerDiscreteScheduler()
+    sched.set_timesteps(25)
+    loop = DenoiseLoop(unet, cn, use_graph=True).begin(**_loop_args(inp, sched.sigmas, sched.timesteps))
+    loop.step()
+    assert_north_star(loop.result().cpu().reshape(lat_ref.shape), lat_ref, "256x384 latents after the fused step (TT_F32)")
+    # ---- 16-bit storage: network contribution by relative L2, graph replay == eager launches
+    sample = inp["latents"].double()
+    share = float(sched.sigmas[1]) / float(sched.sigmas[0])
+    contrib = lambda z: (z.double().reshape(sample.shape) - sample * share).float()
+    for dtype, rel, cos in ((torch.float16, 4e-3, 0.99999), (torch.bfloat16, 3e-2, 0.9995)):
+        pu, pc = _product(full, dtype)
+        got = {}
+        for graph in (True, False):
+            lp = DenoiseLoop(pu, pc, use_graph=graph).begin(**_loop_args(inp, sched.sigmas, sched.timesteps))
+            lp.step()
+            got[graph] = lp.result().clone().cpu()
+        assert torch.equal(got[True], got[False]), "graph replay must equal eager launches at 256x384"
+        st = err_stats(contrib(got[True]), contrib(lat_ref))
+        print(f"256x384 VGL, {dtype}, network contribution to the latents after step 1 vs fp32 oracle: {st}")
+        assert st["ref_absmax"] > 0.1 and st["rel_l2"] <= rel and st["cos"] >= cos, st
+
+
+@torch.no_grad()
 def test_full_size_two_steps_with_fp8_attention_match_oracle(full):
     """BASELINE config 5's precision mode (``attention_fp8``: spatial self-attention on e4m3 operands, everything else bf16)
     against the fp32 ORACLE, not against the HIP bf16 step: two fused VGL steps at 32x56 on the fixture's weights and inputs.

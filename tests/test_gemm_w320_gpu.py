@@ -341,3 +341,18 @@ def test_split_k_without_workspace_falls_back_to_the_tiled_plan(ops, monkeypatch
     ref = F.conv2d(x.float(), wt.float(), None, padding=1).permute(0, 2, 3, 1).reshape(-1, cout)
     close(split, ref, dtype, scale=2.0)
     close(plain, ref, dtype, scale=2.0)
+
+
+@pytest.mark.parametrize("dtype", DTYPES16)
+@pytest.mark.parametrize("m,n,k", [(50176, 320, 320), (50176 - 77, 320, 128), (25088, 320, 320), (12544, 640, 128)])
+def test_linear_even_odd_row_vector(ops, dtype, m, n, k):
+    """rowvec_rows = 1, rowvec_mod = 2 on the big-tile kernels (the merged output projection of the temporal block's two context
+    classes at the finest level): against torch fp32 and against the tiled kernel on the same operands."""
+    a, w = rnd(m, k, dtype=dtype, seed=1).cuda(), rnd(n, k, dtype=dtype, seed=2, scale=k ** -0.5).cuda()
+    bias, rv = rnd(n, dtype=torch.float32, seed=3).cuda(), rnd(2, n, dtype=torch.float32, seed=4).cuda()
+    res = rnd(m, n, dtype=dtype, seed=5).cuda()
+    out, tiled, name = both(ops, a, w, bias=bias, rowvec=rv, rowvec_rows=1, rowvec_mod=2, residual=res)
+    assert "gemm_w320" in name, name
+    ref = a.float() @ w.float().T + bias + rv[torch.arange(m, device="cuda") % 2] + res.float()
+    close(out, ref.cpu(), dtype, scale=2.0)
+    same_as_tiled(out, tiled, dtype)

@@ -885,3 +885,33 @@ def test_gemm_split_k_is_used_and_exact(ops, dtype):
     assert torch.equal(a, b), "split-K must be bit-reproducible"
     ref = F.conv2d(x.float(), wt.float(), bias, padding=1).permute(0, 2, 3, 1).reshape(-1, cout) + res.float()
     close(a, ref, dtype, scale=2.0)
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("m,n,k,rows_per,mod", [(1000, 320, 320, 1, 2),      # even / odd rows (the temporal block's two context classes)
+                                                (12544 - 3, 640, 640, 1, 2), (3136, 1280, 1280, 1, 2), (784, 1280, 1280, 1, 2),
+                                                (300, 128, 5120, 1, 2),      # split-K reduction path
+                                                (1000, 320, 64, 1, 3),       # general small period: per-row loads
+                                                (1000, 320, 64, 50, 3), (4096, 256, 128, 64, 2)])     # wrapped groups of >= 32 rows
+def test_gemm_periodic_row_vector(ops, dtype, m, n, k, rows_per, mod):
+    """TtGemmArgs.rowvec_mod: row r takes rowvec[(r / rowvec_rows) % rowvec_mod] -- against torch, with residual, in place and out of place
+    bit for bit; the even / odd form must equal two launches on the strided row views (what the temporal block ran before)."""
+    a, w = rnd(m, k, dtype=dtype, seed=1), rnd(n, k, dtype=dtype, seed=2, scale=k ** -0.5)
+    bias, rv = rnd(n, dtype=torch.float32, seed=3), rnd(mod, n, dtype=torch.float32, seed=4)
+    res = rnd(m, n, dtype=dtype, seed=5)
+    ad, wd, bd, rd = a.cuda(), w.cuda(), bias.cuda(), rv.cuda()
+    out = ops.gemm(ad, wd, bias=bd, rowvec=rd, rowvec_rows=rows_per, rowvec_mod=mod, residual=res.cuda())
+    idx = (torch.arange(m) // rows_per) % mod
+    ref = a.float() @ w.float().T + bias + rv[idx] + res.float()
+    close(out, ref, dtype, scale=2.0)
+    inplace = res.cuda().clone()
+    ops.gemm(ad, wd, bias=bd, rowvec=rd, rowvec_rows=rows_per, rowvec_mod=mod, residual=inplace, out=inplace)
+    assert torch.equal(inplace, out)
+    if rows_per == 1 and mod == 2 and m % 2 == 0:
+        two = res.cuda().clone()
+        for cls in range(2):
+            ops.gemm(ad[cls::2], wd, bias=(bias + rv[cls]).cuda(), residual=two[cls::2], out=two[cls::2])
+        tol = TOL[dtype]
+        torch.testing.assert_close(out.float(), two.float(), rtol=tol["rtol"], atol=tol["atol"])
+    with pytest.raises(RuntimeError):
+        ops.gemm(ad, wd, bias=bd, rowvec=rd[:1], rowvec_rows=rows_per, rowvec_mod=mod)          # fewer vectors than the period

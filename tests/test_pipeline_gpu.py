@@ -182,3 +182,73 @@ def test_hub_folder_round_trip_runs_like_inference_py(parts, tmp_path):
     assert torch.isfinite(outs[0]).all()
     assert torch.equal(outs[0], outs[1]), "models reloaded from the folder must reproduce the in-memory models bit for bit"
     assert torch.equal(outs[0], outs[2]), "... also from a sharded checkpoint"
+
+
+@torch.no_grad()
+def test_vgl_pipeline_call_produces_frames_through_the_native_vae():
+    """`pipe(image, condition_img, controlnet, ..., output_type="np")` END TO END with the native temporal VAE as the pipeline's
+    one `vae=` object (test_code/inference.py:169-176,241-257): its encode() is the caller's stock encoder (a stub here), the
+    denoise loop is the fused HIP loop, decode_latents (reference :257-283) runs the native decoder in chunks.  In the
+    reference-precision mode (TT_F32) the frames must agree with the oracle loop + oracle/vae.py on the same request constants
+    to the north-star tolerance on every pixel."""
+    from oracle import vae as ov
+    from oracle.scheduler import EulerDiscreteScheduler as OSched, denoise_loop
+    from tests.parity_common import assert_north_star
+    from this_and_that_vdm_amd.svd import EulerDiscreteScheduler, StableVideoDiffusionControlNetPipeline
+    from this_and_that_vdm_amd.svd.autoencoder_kl_temporal_decoder import AutoencoderKLTemporalDecoder
+    from this_and_that_vdm_amd.svd.pipeline_utils import tensor2vid
+    from this_and_that_vdm_amd.utils.synthetic import fill_parameters_
+    if not torch.cuda.is_available():
+        pytest.skip("needs a GPU")
+    dt = torch.float32
+    p_unet, p_cn, o_unet, o_cn = build_pair("tiny_vgl", dt, "cuda:0", True)
+    cfg = dict(block_out_channels=(32, 64, 64, 64), layers_per_block=2)
+    o_vae = ov.AutoencoderKLTemporalDecoder(**cfg).eval()
+    fill_parameters_(o_vae, "vae.", round_to=dt)
+    stock, clip, txt = StubVAE().cuda(), StubCLIPVision().cuda(), StubTextEncoder().cuda()
+    vae = AutoencoderKLTemporalDecoder(**cfg, encoder=stock).eval()
+    vae.load_state_dict(o_vae.state_dict())
+    vae = vae.to("cuda:0")
+    vae.compute_dtype = torch.float32
+    pipe = StableVideoDiffusionControlNetPipeline.from_pretrained(None, vae=vae, image_encoder=clip, unet=p_unet,
+                                                                  scheduler=EulerDiscreteScheduler())
+    pipe.set_progress_bar_config(disable=True)
+    image, cond, ids = _request()
+    lat0 = torch.randn(1, 4, 4, 8, 16, generator=torch.Generator().manual_seed(5))
+    call = dict(prompt=ids.cuda(), use_text=True, text_encoder=txt, height=64, width=128, num_frames=4, num_inference_steps=3, fps=7,
+                motion_bucket_id=200, noise_aug_strength=0.0, guess_mode=False, decode_chunk_size=3)
+    frames = pipe(image.cuda(), cond, p_cn, latents=lat0.clone(), output_type="np", **call).frames
+    assert frames.shape == (1, 4, 64, 128, 3) and np.isfinite(frames).all()
+    # the oracle on the same request constants: loop -> / scaling_factor -> chunked decode -> the same post-processing
+    ehs = pipe.encode_clip(image.cuda(), ids.cuda(), True, txt, "cuda", 1, True).float().cpu()
+    img = pipe.image_processor.preprocess(image, 64, 128)
+    il = pipe._encode_vae_image(img.cuda(), "cuda", 1, True).float().cpu().unsqueeze(1).repeat(1, 4, 1, 1, 1)
+    ges = stock.encode(torch.from_numpy(cond).cuda().half().float()).latent_dist.mode().float().cpu()   # quirk Q7: fp16 gesture frames
+    sched = OSched()
+    sched.set_timesteps(3)
+    lat = denoise_loop(o_unet, o_cn, sched, lat0 * sched.init_noise_sigma, il, ehs, torch.tensor([[6.0, 200.0, 0.0]] * 2), ges,
+                       torch.linspace(1, 3, 4).view(1, 4, 1, 1, 1), num_inference_steps=3)
+    z = lat.flatten(0, 1) / o_vae.scaling_factor
+    ref = torch.cat([o_vae.decode(z[:3], num_frames=3), o_vae.decode(z[3:], num_frames=1)], 0)
+    ref = ref.reshape(1, 4, *ref.shape[1:]).permute(0, 2, 1, 3, 4)
+    ref_frames = tensor2vid(ref, pipe.image_processor, output_type="np")
+    # latents first (the loop), then the frames (loop + native decoder + post-processing, values in [0, 1])
+    got_lat = pipe(image.cuda(), cond, p_cn, latents=lat0.clone(), output_type="latent", **call).frames
+    assert_north_star(got_lat, lat, "pipeline latents (TT_F32) vs oracle loop")
+    st = err_stats(torch.from_numpy(frames), torch.from_numpy(ref_frames))
+    print("pipeline frames through the native VAE vs oracle loop + oracle/vae.py:", st)
+    assert_north_star(torch.from_numpy(frames), torch.from_numpy(ref_frames), "pipeline frames through the native VAE (TT_F32)")
+    # and the same call in fp16 storage (the reference's inference dtype) runs end to end: finite frames close to the fp32 ones
+    vae16 = AutoencoderKLTemporalDecoder(**cfg, encoder=StubVAE().cuda().half()).eval()
+    vae16.load_state_dict(o_vae.state_dict())
+    vae16 = vae16.to("cuda:0", torch.float16)
+    p16, c16, _, _ = build_pair("tiny_vgl", torch.float16, "cuda:0", True)
+    pipe16 = StableVideoDiffusionControlNetPipeline.from_pretrained(None, vae=vae16, image_encoder=StubCLIPVision().cuda().half(), unet=p16,
+                                                                    scheduler=EulerDiscreteScheduler())
+    pipe16.set_progress_bar_config(disable=True)
+    call16 = dict(call, text_encoder=StubTextEncoder().cuda().half())
+    f16 = pipe16(image.cuda(), cond, c16, latents=lat0.clone(), output_type="np", **call16).frames
+    assert f16.shape == frames.shape and np.isfinite(f16).all()
+    assert vae16.dtype == torch.float16                      # force_upcast round trip (config.force_upcast = True) restored the dtype
+    print("fp16 frames vs TT_F32 frames: max abs", float(np.abs(f16 - frames).max()))
+    assert float(np.abs(f16 - frames).max()) <= 0.05

@@ -42,5 +42,33 @@ def test_full_checkpoint_state_dict_loads_and_cpu_is_refused():
     assert not missing and not unexpected
     with pytest.raises(RuntimeError, match="no CPU fallback"):
         p.decode(torch.zeros(3, 4, 8, 4), num_frames=3)
-    with pytest.raises(NotImplementedError):
+    with pytest.raises(NotImplementedError, match="no stock encoder"):
         p.encode(torch.zeros(1, 3, 64, 32))
+
+
+def test_encode_is_delegated_to_the_stock_encoder_given_as_vae_argument(tmp_path):
+    """One object for the pipeline's `vae=` (test_code/inference.py:169-176): encode() goes to the caller's stock module, which
+    is neither a sub-module (state dict / parameters stay the decoder's) nor a config entry, but follows .to() / .half() -- the
+    pipeline's force_upcast round trip (reference :556-571) must move the encoder as well."""
+    from tests.stubs import StubVAE
+    stock = StubVAE()
+    p = AutoencoderKLTemporalDecoder(**CFG, encoder=stock)
+    assert "encoder" not in p.config and p.config.force_upcast is True
+    assert all(k.startswith("decoder.") for k in p.state_dict()) and all(q is not w for q in p.parameters() for w in stock.parameters())
+    x = torch.rand(2, 3, 32, 16)
+    assert torch.equal(p.encode(x).latent_dist.mode(), stock.encode(x).latent_dist.mode())
+    p.half()
+    assert stock.enc.weight.dtype == torch.float16 and p.dtype == torch.float16
+    p.to(dtype=torch.float32)
+    assert stock.enc.weight.dtype == torch.float32 and p.dtype == torch.float32
+    # save_pretrained / from_pretrained(..., encoder=) round trip: config.json holds no module, the encoder is re-attached
+    p.save_pretrained(str(tmp_path))
+    q = AutoencoderKLTemporalDecoder.from_pretrained(str(tmp_path), encoder=stock)
+    assert torch.equal(q.encode(x).latent_dist.mode(), stock.encode(x).latent_dist.mode())
+    for (k, a), (_, b) in zip(p.state_dict().items(), q.state_dict().items()):
+        assert torch.equal(a, b), k
+    with pytest.raises(TypeError):
+        AutoencoderKLTemporalDecoder(**CFG, encoder=torch.nn.Identity())
+    assert q.with_encoder(None) is q
+    with pytest.raises(NotImplementedError):
+        q.encode(x)

@@ -28,6 +28,7 @@ class TtGemmArgs(C.Structure):
         ("out_col_hw", C.c_int32), ("out_col_hwp", C.c_int32), ("dtype", C.c_int32),
         ("ws", C.c_void_p), ("ws_bytes", C.c_int64),
         ("ln_fold", C.c_int32), ("ln_eps", C.c_float), ("out_fp8", C.c_int32),
+        ("rowvec_mod", C.c_int32),          # ABI 7: periodic row vector
     ]
 
 
@@ -122,7 +123,7 @@ def load():
     for name, (res, args) in SIGNATURES.items():
         fn = getattr(lib, name)          # AttributeError here == ABI mismatch with include/ttvdm.h
         fn.restype, fn.argtypes = res, args
-    if lib.tt_abi_version() != 6:
+    if lib.tt_abi_version() != 7:
         raise RuntimeError("libttvdm.so ABI version mismatch")
     _lib = lib
     return lib

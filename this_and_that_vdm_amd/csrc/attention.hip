@@ -89,6 +89,7 @@ __device__ __forceinline__ Bid3 xcd_remap3() {
 // half hi is head dimension 16 (2j + t) + 8 hi + s -- what the K fragment of that step holds.  No Q tensor, no separate launch.
 template <typename Tag, int D, int MASK, bool QP = false>
 __global__ __launch_bounds__(256, (D == 64 && Elem<Tag>::ES == 2) ? 2 : 1) void attn_kernel(const AttnP p) {
+  kernarg_touch<sizeof(AttnP)>();
   extern __shared__ __attribute__((aligned(16))) char smem[];
   typedef typename Elem<Tag>::quad_t quad_t;
   constexpr int ES = Elem<Tag>::ES, EPC = Elem<Tag>::EPC;   // bytes per element, elements per 16-byte chunk
@@ -465,6 +466,7 @@ __global__ __launch_bounds__(256, (D == 64 && Elem<Tag>::ES == 2) ? 2 : 1) void 
 typedef long fp8x8_t;
 template <typename Tag, int D>
 __global__ __launch_bounds__(256, 2) void attn8_kernel(const AttnP p) {
+  kernarg_touch<sizeof(AttnP)>();
   extern __shared__ __attribute__((aligned(16))) char smem[];
   typedef typename Elem<Tag>::quad_t quad_t;
   constexpr int ES = Elem<Tag>::ES;             // OUTPUT element size

@@ -231,4 +231,19 @@ template <int N> __device__ __forceinline__ void lds_wait() {
   __builtin_amdgcn_sched_barrier(0);
 }
 
+// ---------------------------------------------------------------- kernel-argument warm-up
+// hipcc loads the kernel arguments where they are first needed: a kernel with a few hundred bytes of them meets 3-5 SERIALISED
+// scalar-cache misses (s_load ... s_waitcnt lgkmcnt(0), ~0.3-0.5 us each when the line comes from L2 / the fabric) before its first
+// global load -- measured with the TT_GEMM_TIMELINE stamps: 2.0 us of "prologue" for ~140 scalar instructions.
+// kernarg_touch<BYTES>() reads one dword of every 64-byte line of the argument segment in ONE batch at kernel entry; the first wait
+// then covers all of them and every later s_load hits the scalar cache.
+template <int BYTES> __device__ __forceinline__ void kernarg_touch() {
+  typedef const __attribute__((address_space(4))) unsigned* kptr_t;
+  kptr_t ka = (kptr_t)__builtin_amdgcn_kernarg_segment_ptr();
+  unsigned acc = 0;
+#pragma unroll
+  for (int off = 0; off < BYTES; off += 64) acc |= ka[off / 4];
+  asm volatile("" ::"s"(acc));
+}
+
 static inline int ceil_div(long a, long b) { return (int)((a + b - 1) / b); }

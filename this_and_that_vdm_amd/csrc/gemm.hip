@@ -195,7 +195,7 @@ static bool w320_eligible(const TtGemmArgs* a) {
       a->out_fp8 || a->out_f32 || a->out_col_hw || a->ln_fold > 1 || (a->ln_fold && (a->mode != 0 || a->k1)))
     return false;
   if (a->mode == 1 && (a->stride != 1 || a->upsample || a->hin != a->hout || a->win != a->wout || a->win >= 32768 || a->hin >= 32768)) return false;
-  if (a->rowvec && a->rowvec_rows < 32) return false;
+  if (a->rowvec && a->rowvec_rows < 32 && !(a->rowvec_rows == 1 && a->rowvec_mod == 2)) return false;
   // 8-byte (16-bit operands) / 16-byte (fp32 vectors) epilogue accesses
   if ((a->ldo & 3) || (a->residual && (a->ld_res & 3)) || (a->blend && (a->ld_blend & 3)) || (a->rowvec && (a->ld_rowvec & 3))) return false;
   if ((((size_t)a->out | (size_t)a->residual | (size_t)a->blend) & 7) || (((size_t)a->rowvec | (size_t)a->bias) & 15)) return false;
@@ -210,6 +210,11 @@ static int w320_force() {                                    // tuning aid: TT_W
 // less than 70 % of a round, e.g. the second UNet level at 32x56 latents -- 12544 rows, N = 640: 98 x 2 = 196 tiles of 128 rows).
 // By default the variant takes conv3x3 problems only: A/B in the step 31.06 (256-row kernel only) / 31.01 (variant for all modes) /
 // 30.84 ms (variant for the convs); in isolation +9..16 % on the convs, +-0 on the linears and temporal convs (tools/w320_bench.py).
+static int w320_min_fill() {                                 // percent of the CU x round slots the tiles must fill (TT_W320_MIN_FILL, A/B)
+  static int fill = -1;
+  if (fill < 0) { const char* e = getenv("TT_W320_MIN_FILL"); fill = e ? atoi(e) : 60; }
+  return fill;
+}
 int w320_route(const TtGemmArgs* a) {
   if (!w320_eligible(a)) return 0;
   if (w320_force() == 1 || w320_force() == 2) return w320_force();
@@ -217,7 +222,7 @@ int w320_route(const TtGemmArgs* a) {
     if (half && (!(g_w320 & 2) || ((g_w320 & 4) && a->mode != 1))) break;     // tt_gemm_set_big_tile(2): the 256-row kernel only
     const long tiles = (long)ceil_div(a->m, half ? 128 : 256) * (a->n / 320);
     const long rounds = (tiles + 255) / 256;
-    if (tiles * 100 >= rounds * 256 * 70) return 1 + half;   // >= 70 % of the CU x round slots busy (196 / 392 / 588 / 784 tiles: 77 %)
+    if (tiles * 100 >= rounds * 256 * w320_min_fill()) return 1 + half;   // >= 70 % of the CU x round slots busy (196 / 392 / 588 / 784 tiles: 77 %)
   }
   return 0;
 }
@@ -332,6 +337,7 @@ extern "C" int tt_gemm(const TtGemmArgs* a, tt_stream_t stream) {
   if (a->geglu && ((a->n & 15) || a->residual || a->blend || a->rowvec || a->out_f32 || a->out_col_hw))
     TT_FAIL(TT_EINVAL, "tt_gemm: geglu needs n %% 16 == 0 and no other epilogue terms");
   if (a->rowvec && a->rowvec_rows <= 0) TT_FAIL(TT_EINVAL, "tt_gemm: rowvec_rows");
+  if (a->rowvec_mod < 0 || (a->rowvec_mod > 0 && !a->rowvec)) TT_FAIL(TT_EINVAL, "tt_gemm: rowvec_mod %d (>= 0, needs rowvec)", a->rowvec_mod);
   if (a->ln_fold < 0 || a->ln_fold > 2) TT_FAIL(TT_EINVAL, "tt_gemm: ln_fold %d (0 none, 1 rows of A, 2 rows of W)", a->ln_fold);
   if (a->ln_fold && (a->mode != 0 || a->k1 != 0 || !(a->ln_eps > 0.f)))
     TT_FAIL(TT_EINVAL, "tt_gemm: ln_fold needs mode 0, one source spanning the whole LayerNorm row (k0 = C) and ln_eps > 0");
@@ -345,7 +351,7 @@ extern "C" int tt_gemm(const TtGemmArgs* a, tt_stream_t stream) {
   p.nimg = a->nimg; p.hin = a->hin; p.win = a->win; p.hout = a->hout; p.wout = a->wout;
   p.stride = a->stride; p.upsample = a->upsample; p.frames = a->frames; p.hw = a->hw;
   p.bias = a->bias; p.acc_scale = a->acc_scale;
-  p.rowvec = a->rowvec; p.rowvec_rows = a->rowvec_rows; p.ld_rowvec = a->ld_rowvec;
+  p.rowvec = a->rowvec; p.rowvec_rows = a->rowvec_rows; p.ld_rowvec = a->ld_rowvec; p.rowvec_mod = a->rowvec ? a->rowvec_mod : 0;
   p.geglu = a->geglu; p.residual = (const char*)a->residual; p.ld_res = a->ld_res;
   p.blend = (const char*)a->blend; p.ld_blend = a->ld_blend; p.alpha = a->alpha;
   const int es = a->dtype == TT_F32 ? 4 : 2;         // bytes per stored element
@@ -373,7 +379,9 @@ extern "C" int tt_gemm(const TtGemmArgs* a, tt_stream_t stream) {
     const long outb = ((long)(p.m - 1) * p.ldo + (p.out_col_hw > 0 ? p.ldo : n_out)) * (p.out_f32 ? 4 : (p.out_fp8 ? 1 : es));
     const long resb = p.residual ? ((long)(p.m - 1) * p.ld_res + p.n) * es : 0;
     const long blb = p.blend ? ((long)(p.m - 1) * p.ld_blend + p.n) * es : 0;
-    const long rvb = p.rowvec ? ((long)((p.m - 1) / p.rowvec_rows) * p.ld_rowvec + p.n) * 4 : 0;
+    long rv_last = p.rowvec ? (p.m - 1) / p.rowvec_rows : 0;             // last row-vector index the kernel can form
+    if (p.rowvec_mod > 0 && rv_last > p.rowvec_mod - 1) rv_last = p.rowvec_mod - 1;
+    const long rvb = p.rowvec ? (rv_last * p.ld_rowvec + p.n) * 4 : 0;
     if (outb >= (1L << 31) || resb >= (1L << 31) || blb >= (1L << 31) || rvb >= (1L << 31))
       TT_FAIL(TT_EUNSUPPORTED, "tt_gemm: epilogue operand larger than 2 GiB (32-bit buffer offsets)");
     p.out_bytes = (unsigned)outb; p.res_bytes = (unsigned)resb; p.blend_bytes = (unsigned)blb;

@@ -8,6 +8,23 @@
 namespace ttg {
 
 
+// Division by a launch-uniform divisor without the ~25-instruction software sequence (x2 for the remainder): the tiled template
+// ran ~500 scalar instructions before its first load, most of them integer divisions, and the scalar unit is shared by all waves
+// of a CU -- 16 waves x 500 instructions ~ 2.4 us of every launch (tools/gemm_timeline.py).
+//   q = floor(n / d) = (n * mul) >> sh   for 0 <= n < 2^31, 1 <= d < 2^31,  mul = ceil(2^(31 + l) / d), sh = 31 + l, l = ceil(log2 d)
+// (Granlund-Montgomery with N = 31: exact; mul <= 2^32 only for d = 1 ... handled: l = 0 -> mul = 2^31, sh = 31.)
+struct FastDiv { unsigned mul, sh; };
+static inline FastDiv make_fastdiv(long d_) {
+  unsigned long long d = d_ < 1 ? 1 : (unsigned long long)d_;
+  unsigned l = 0;
+  while ((1ull << l) < d) ++l;
+  FastDiv f;
+  f.mul = (unsigned)(((1ull << (31 + l)) + d - 1) / d);
+  f.sh = 31 + l;
+  return f;
+}
+__device__ __forceinline__ int fdiv(int n, const FastDiv& f) { return (int)(((unsigned long long)(unsigned)n * f.mul) >> f.sh); }
+
 struct GemmP {
   const char* a0; const char* a1;
   int k0, k1; long lda0, lda1;
@@ -17,6 +34,7 @@ struct GemmP {
   int frames, hw;
   const float* bias; float acc_scale;
   const float* rowvec; int rowvec_rows; long ld_rowvec;
+  int rowvec_mod;                   // > 0: row m takes rowvec[(m / rowvec_rows) % rowvec_mod] (TtGemmArgs.rowvec_mod)
   int geglu;
   const char* residual; long ld_res;
   const char* blend; long ld_blend; float alpha;
@@ -32,6 +50,8 @@ struct GemmP {
   float* ws;                        // [splitk][m][n] fp32 partial sums
   int ln_fold; float ln_eps;        // fused LayerNorm of the A rows (1) / W rows (2): see gemm_kernel, MODE 3 / 4
   int out_fp8;                      // store e4m3 bytes (operands of the fp8 attention path) instead of 16-bit values
+  // launch-uniform divisors of the tiled template as multiply-shift pairs (fill_fastdivs, called by launch_cfg)
+  FastDiv fd_splitk, fd_per_group, fd_group_m, fd_last_rows, fd_per_tap, fd_hwo, fd_wout, fd_hw, fd_frames, fd_rv_rows, fd_rv_mod;
 };
 
 // 4 floats -> 4 OCP e4m3 bytes (saturating at +-448: e4m3fn has no infinity, an overflow would become NaN)
@@ -149,7 +169,9 @@ __device__ __forceinline__ void epilogue_quad(const GemmP& p, int gm, int gn, fl
 #pragma unroll
   for (int e = 0; e < 4; ++e) v[e] *= p.acc_scale;
   if (p.rowvec) {
-    const float4 b = *(const float4*)(p.rowvec + (long)(gm / p.rowvec_rows) * p.ld_rowvec + gn);
+    int rg = gm / p.rowvec_rows;
+    if (p.rowvec_mod > 0) rg %= p.rowvec_mod;
+    const float4 b = *(const float4*)(p.rowvec + (long)rg * p.ld_rowvec + gn);
     v[0] += b.x; v[1] += b.y; v[2] += b.z; v[3] += b.w;
   }
   if (p.residual) {
@@ -229,6 +251,7 @@ void gemm_kernel(const GemmP p) {
   constexpr int MODE = KMODE >= 3 ? 0 : KMODE;         // gather mode
   constexpr int LN = KMODE >= 3 ? KMODE - 2 : 0;       // 0 none, 1 statistics of A rows, 2 of W rows
   TL(0);
+  kernarg_touch<sizeof(GemmP)>();
   typedef typename Elem<Tag>::quad_t quad_t;
   constexpr int ES = Elem<Tag>::ES, EPC = Elem<Tag>::EPC;   // bytes per element, elements per 16-byte chunk
   constexpr int NT = 64 * WGM * WGN;                   // threads
@@ -253,8 +276,8 @@ void gemm_kernel(const GemmP p) {
     const int nwg = gridDim.x, q = nwg >> 3, r = nwg & 7, xcd = bid & 7, idx = bid >> 3;
     bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
   }
-  const int split = p.splitk > 1 ? bid % p.splitk : 0;      // slices of one tile sit next to each other
-  if (p.splitk > 1) bid /= p.splitk;
+  int split = 0;                                            // slices of one tile sit next to each other
+  if (p.splitk > 1) { const int t = fdiv(bid, p.fd_splitk); split = bid - t * p.splitk; bid = t; }
   // Within an XCD's run the tiles go in groups of `group_m` tile rows, column by column inside a group: the ~64 workgroups
   // that are resident on an XCD at a time then cover group_m rows x 64/group_m columns, i.e. every K slice they fetch is
   // shared by group_m (W) or 64/group_m (A) of them instead of the whole window sharing ONE A row and streaming every W
@@ -264,17 +287,20 @@ void gemm_kernel(const GemmP p) {
   {
     const int gm = p.group_m;
     const int per_group = gm * p.tiles_n;
-    const int grp = bid / per_group;
+    const int grp = fdiv(bid, p.fd_per_group);
     const int first = grp * gm;
-    const int rows = min(gm, p.tiles_m - first);
     const int r = bid - grp * per_group;
-    tile_n = r / rows;
+    // every group has gm tile rows except a ragged last one (tiles_m % gm rows): two precomputed divisors
+    const bool full = first + gm <= p.tiles_m;
+    const int rows = full ? gm : p.tiles_m - first;
+    tile_n = full ? fdiv(r, p.fd_group_m) : fdiv(r, p.fd_last_rows);
     tile_m = first + (r - tile_n * rows);
   }
   const int m0 = tile_m * BM, n0 = tile_n * BN;
   // K-tile range of this block
-  const int kt_lo = (int)((long)p.kt_total * split / p.splitk);
-  const int KT = (int)((long)p.kt_total * (split + 1) / p.splitk) - kt_lo;
+  // (kt_total * splitk < 2^31: at most a few thousand K steps, splitk <= 16)
+  const int kt_lo = p.splitk > 1 ? fdiv(p.kt_total * split, p.fd_splitk) : 0;
+  const int KT = p.splitk > 1 ? fdiv(p.kt_total * (split + 1), p.fd_splitk) - kt_lo : p.kt_total;
 
   // ---- staging: buffer_load ... lds through 128-bit resource descriptors.  Every lane owns a 32-bit byte offset per
   // staged 16-byte chunk (computed once per tile, or once per conv tap); the K position is a SCALAR offset.  Lanes that
@@ -305,12 +331,13 @@ void gemm_kernel(const GemmP p) {
       }
     } else if constexpr (MODE == 1) {
       const int hwo = p.hout * p.wout;
-      a_img[i] = g / hwo;
+      a_img[i] = fdiv(g, p.fd_hwo);
       const int rem = g - a_img[i] * hwo;
-      a_y[i] = rem / p.wout;
+      a_y[i] = fdiv(rem, p.fd_wout);
       a_x[i] = rem - a_y[i] * p.wout;
     } else {
-      a_img[i] = (g / p.hw) % p.frames;   // frame index
+      const int fr = fdiv(g, p.fd_hw);
+      a_img[i] = fr - fdiv(fr, p.fd_frames) * p.frames;   // frame index
       a_y[i] = g;                         // row
     }
   }
@@ -327,7 +354,7 @@ void gemm_kernel(const GemmP p) {
   int s_tap, s_src, s_kc;
   {
     const int per_tap = p.nk0 + p.nk1;
-    s_tap = kt_lo / per_tap;
+    s_tap = kt_lo ? fdiv(kt_lo, p.fd_per_tap) : 0;
     const int rem = kt_lo - s_tap * per_tap;
     s_src = rem >= p.nk0 ? 1 : 0;
     s_kc = rem - (s_src ? p.nk0 : 0);
@@ -476,7 +503,17 @@ void gemm_kernel(const GemmP p) {
   const bool direct = (p.out_col_hw > 0 || p.out_f32) && p.splitk == 1;   // rare layouts keep the simple per-fragment path
   const bool blend_is_res = p.blend && p.blend == p.residual && p.ld_blend == p.ld_res;
   auto preload_residual = [&]() {
-    if constexpr (EARLY_RES) if (!direct && !p.geglu && p.splitk == 1) {
+    if constexpr (EARLY_RES) {
+#pragma unroll
+      for (int i = 0; i < FM; ++i)
+#pragma unroll
+        for (int c = 0; c < NCH; ++c)
+#pragma unroll
+          for (int pass = 0; pass < 8; ++pass) resv[i][c][pass] = zero_quad<Tag>();
+    }
+    // (no residual: nothing is requested -- loads through a 0-byte descriptor return 0, but still cost their issue slots in the
+    // texture addresser: 0.5 us per launch for two resident 128 x 128 tiles, tools/gemm_timeline.py)
+    if constexpr (EARLY_RES) if (!direct && !p.geglu && p.splitk == 1 && p.residual) {
       const __amdgpu_buffer_rsrc_t r_res = make_rsrc(p.residual, p.res_bytes);
 #pragma unroll
       for (int i = 0; i < FM; ++i)
@@ -499,7 +536,11 @@ void gemm_kernel(const GemmP p) {
   if constexpr (NST == 2) {
     // plain double buffer: wait tile kt, barrier, issue tile kt+1, compute tile kt.  The first tile is requested before
     // the residual batch (whose address arithmetic costs ~2 us); the first wait covers both.
+    TL(6);
     stage(0);
+    TL(7);
+    // (requested behind the SECOND tile instead -- under the MFMAs of the first K step -- the batch disturbs the K loop's DMA stream:
+    // 12544 x 640 x 640 + residual 18.7 -> 19.3 us, K = 2560 49.3 -> 51.9 us, step 30.67 -> 30.72 ms, one call; round 5)
     preload_residual();
     TL(1);
     for (int kt = 0; kt < KT; ++kt) {
@@ -525,6 +566,7 @@ void gemm_kernel(const GemmP p) {
       }
     }
   } else {
+    TL(6);
     preload_residual();                       // before the ring fill: the counted waits below assume the DMAs come last
     TL(1);
     // software pipeline: fragments double-buffered in registers; the wait+barrier for tile kt+1 sits BEFORE the last
@@ -641,11 +683,16 @@ void gemm_kernel(const GemmP p) {
         const __amdgpu_buffer_rsrc_t r_bl = make_rsrc(p.blend, INPASS ? p.blend_bytes : 0);
         const __amdgpu_buffer_rsrc_t r_res = make_rsrc(p.residual, (INPASS && !EARLY_RES) ? p.res_bytes : 0);
         const int rv_rows = p.rowvec ? p.rowvec_rows : 1;
+        // periodic row vector (rowvec_mod): group indices wrap; the even / odd form (one row per group, period 2) stays on the
+        // two-vector path below with the row's parity as the selector
+        const bool parity = FILM && p.rowvec_mod == 2 && rv_rows == 1;
+        auto wrap = [&](int g) { return p.rowvec_mod > 0 ? g - fdiv(g, p.fd_rv_mod) * p.rowvec_mod : g; };
 #pragma unroll
         for (int i = 0; i < FM; ++i) {
           const int mb = m0 + wr * WTM + i * 32;
-          const int grp0 = mb / rv_rows;                 // row group of the fragment's first row (uniform)
-          const int grp_split = (grp0 + 1) * rv_rows;    // first row of the next group
+          const int grp_raw = fdiv(mb, p.fd_rv_rows);    // row group of the fragment's first row (uniform)
+          const int grp0 = parity ? 0 : wrap(grp_raw), grp1 = parity ? 1 : wrap(grp_raw + 1);
+          const int grp_split = parity ? mb : (grp_raw + 1) * rv_rows;    // first row of the next group (parity: see the selector)
 #pragma unroll
           for (int jc = 0; jc < FN; jc += 2) {
             const int nfr = (jc + 1 < FN) ? 2 : 1;       // fragments in this chunk (compile-time after unrolling)
@@ -659,7 +706,7 @@ void gemm_kernel(const GemmP p) {
             float4 film_lo = make_float4(0.f, 0.f, 0.f, 0.f), film_hi = film_lo;
             if constexpr (FILM) {
               film_lo = ld128f(r_rv, (mb < p.m && gn < p.n) ? (int)(((long)grp0 * p.ld_rowvec + gn) * 4) : kInv);
-              film_hi = ld128f(r_rv, (grp_split < p.m && gn < p.n) ? (int)(((long)(grp0 + 1) * p.ld_rowvec + gn) * 4) : kInv);
+              film_hi = ld128f(r_rv, (grp_split < p.m && gn < p.n) ? (int)(((long)grp1 * p.ld_rowvec + gn) * 4) : kInv);
             }
 #pragma unroll
             for (int jj = 0; jj < 2; ++jj) {
@@ -686,7 +733,7 @@ void gemm_kernel(const GemmP p) {
                   if constexpr (EARLY_RES) rqv[k] = resv[i][jc / 2][pass];
                   else if constexpr (INPASS) rqv[k] = ldq<Tag>(r_res, ok ? (int)(((long)gm * p.ld_res + gn) * ES) : kInv);
                   if constexpr (INPASS) {
-                    rvv[k] = ld128f(r_rv, ok ? (int)(((long)(gm / rv_rows) * p.ld_rowvec + gn) * 4) : kInv);
+                    rvv[k] = ld128f(r_rv, ok ? (int)(((long)wrap(fdiv(gm, p.fd_rv_rows)) * p.ld_rowvec + gn) * 4) : kInv);
                     blv[k] = ldq<Tag>(r_bl, ok ? (int)(((long)gm * p.ld_blend + gn) * ES) : kInv);
                   }
                 }
@@ -707,7 +754,7 @@ void gemm_kernel(const GemmP p) {
                     const quad_t rq = rqv[k];
                     quad_t bq = rq;
                     if constexpr (FILM) {
-                      const float4 f = gm >= grp_split ? film_hi : film_lo;
+                      const float4 f = (parity ? (gm & 1) != 0 : gm >= grp_split) ? film_hi : film_lo;
                       v[0] += f.x; v[1] += f.y; v[2] += f.z; v[3] += f.w;
                     }
                     if constexpr (INPASS) {
@@ -728,7 +775,8 @@ void gemm_kernel(const GemmP p) {
           }
         }
       };
-      const bool inpass = (p.blend && !blend_is_res) || (p.rowvec && p.rowvec_rows < 32) || (!EARLY_RES && p.residual);
+      const bool inpass = (p.blend && !blend_is_res) || (p.rowvec && p.rowvec_rows < 32 && !(p.rowvec_mod == 2 && p.rowvec_rows == 1)) ||
+                          (!EARLY_RES && p.residual);
       if (inpass) run(std::false_type{}, std::true_type{}, std::false_type{});
       else if (p.rowvec) run(std::true_type{}, std::false_type{}, std::false_type{});
       else if (MODE == 0 && ES == 2 && p.out_fp8) {          // Q | K and V^T of the fp8 attention path (linear, no residual)
@@ -981,6 +1029,7 @@ __global__ __launch_bounds__(SQ_NT) void sq320_kernel(const GemmP p) {
 // split-K second pass: sum the fp32 slabs in a fixed order (bit-reproducible) and run the normal epilogue
 template <typename Tag>
 __global__ __launch_bounds__(256) void splitk_epilogue_kernel(const GemmP p) {
+  kernarg_touch<sizeof(GemmP)>();
   const long quads = (long)p.m * (p.n >> 2);
   const int nq = p.n >> 2;
   for (long q = (long)blockIdx.x * blockDim.x + threadIdx.x; q < quads; q += (long)gridDim.x * blockDim.x) {
@@ -1016,6 +1065,21 @@ void launch_mode(const GemmP& p, hipStream_t st) {
 
 // LNOK: also instantiate the fused-LayerNorm variants (only the tile shapes the planner picks; gemm.hip keeps LayerNorm
 // problems on them)
+// multiply-shift pairs of every launch-uniform divisor the kernel meets (tile order, K split, conv / frame geometry, row groups)
+static inline void fill_fastdivs(GemmP& p) {
+  p.fd_splitk = make_fastdiv(p.splitk);
+  p.fd_per_group = make_fastdiv((long)p.group_m * p.tiles_n);
+  p.fd_group_m = make_fastdiv(p.group_m);
+  p.fd_last_rows = make_fastdiv(p.tiles_m % p.group_m ? p.tiles_m % p.group_m : p.group_m);
+  p.fd_per_tap = make_fastdiv(p.nk0 + p.nk1);
+  p.fd_hwo = make_fastdiv((long)p.hout * p.wout);
+  p.fd_wout = make_fastdiv(p.wout);
+  p.fd_hw = make_fastdiv(p.hw);
+  p.fd_frames = make_fastdiv(p.frames);
+  p.fd_rv_rows = make_fastdiv(p.rowvec ? p.rowvec_rows : 1);
+  p.fd_rv_mod = make_fastdiv(p.rowvec_mod > 0 ? p.rowvec_mod : 1);
+}
+
 template <typename Tag, int BM, int BN, int BK, int NST, int WGM, int WGN, bool LNOK = false>
 void launch_cfg(GemmP& p, hipStream_t st) {
   p.tiles_m = ceil_div(p.m, BM);
@@ -1036,6 +1100,7 @@ void launch_cfg(GemmP& p, hipStream_t st) {
   }
   p.nk0 = ceil_div(p.k0, BK); p.nk1 = p.k1 ? ceil_div(p.k1, BK) : 0;
   p.kt_total = p.taps * (p.nk0 + p.nk1);
+  fill_fastdivs(p);
   if constexpr (LNOK) {
     if (p.ln_fold == 1) { launch_mode<Tag, BM, BN, BK, NST, WGM, WGN, 3>(p, st); return; }
     if (p.ln_fold == 2) { launch_mode<Tag, BM, BN, BK, NST, WGM, WGN, 4>(p, st); return; }

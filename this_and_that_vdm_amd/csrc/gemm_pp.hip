@@ -42,6 +42,7 @@ __device__ __forceinline__ void lds_write8_raw(unsigned addr, unsigned a, unsign
 template <typename Tag, int LNROWS, int GEGLU>
 __global__ __launch_bounds__(512, 2) void gemm_pp_kernel(const GemmP p) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
+  kernarg_touch<sizeof(GemmP)>();
 #ifdef TT_PP_HALF_PROBE   // probe only (never shipped): 128 x 256 tiles = the A-lo half of every quadrant schedule; measures the K-loop rate at 48 KiB of DMA per slab
   constexpr int BM = 128, BN = 256, WTM = 64, WTN = 64, FM = 2, FN = 2, CPR = 8, ES = 2;
   constexpr bool HALF = true;

@@ -63,13 +63,16 @@ __device__ __forceinline__ void w3_epilogue_rows(const GemmP& p, const f32x16_t 
   const __amdgpu_buffer_rsrc_t r_bl = make_rsrc(p.blend, BLEND ? p.blend_bytes : 0);
   const float one_m_alpha = 1.0f - alpha;
   const int rv_rows = FILM ? p.rowvec_rows : 1;
+  const bool parity = FILM && p.rowvec_mod == 2 && rv_rows == 1;             // even / odd rows: two vectors, the row's parity selects
+  auto wrap = [&](int g) { return p.rowvec_mod > 0 ? g % p.rowvec_mod : g; };   // periodic row vector (uniform, once per fragment row)
   auto strip_off = [](int row, int quad, int nq) { return row * 256 + ((quad ^ (row & (nq - 1))) << 4); };
 #pragma unroll
   for (int i = 0; i < NI; ++i) {
   const f32x16_t (&acc)[5] = accs[i];
   const float rs = rss[i];
   const int mb = mb0 + i * 32;
-  const int grp0 = mb / rv_rows, grp_split = (grp0 + 1) * rv_rows;       // row group of the fragment's first row, first row of the next
+  const int grp_raw = mb / rv_rows, grp_split = (grp_raw + 1) * rv_rows;    // row group of the fragment's first row, first row of the next
+  const int grp0 = parity ? 0 : wrap(grp_raw), grp1 = parity ? 1 : wrap(grp_raw + 1);
   // Residual only (the common case: to_out, FF2, proj_out, conv2 + shortcut): ALL 24 loads of the fragment row are issued before
   // the first chunk is processed.  Batch by batch (loads, wait, stores, next loads behind those stores: in-order vmcnt) a wave pays
   // one memory round trip per batch -- 12 per tile, the whole epilogue of a K = 320 problem; up front it pays one (two) per fragment row.
@@ -99,7 +102,7 @@ __device__ __forceinline__ void w3_epilogue_rows(const GemmP& p, const f32x16_t 
     float4 film_lo = make_float4(0.f, 0.f, 0.f, 0.f), film_hi = film_lo;
     if constexpr (FILM) {                                                  // beyond the last group: out of range -> 0
       film_lo = ld128f(r_rv, (int)(((unsigned)grp0 * (unsigned)p.ld_rowvec + (unsigned)gn) * 4u));
-      film_hi = ld128f(r_rv, (int)(((unsigned)(grp0 + 1) * (unsigned)p.ld_rowvec + (unsigned)gn) * 4u));
+      film_hi = ld128f(r_rv, (int)(((unsigned)grp1 * (unsigned)p.ld_rowvec + (unsigned)gn) * 4u));
     }
     if constexpr (XCHG) {
       if (jc) __syncthreads();                               // the partner has consumed the previous chunk's exchange buffer
@@ -151,7 +154,7 @@ __device__ __forceinline__ void w3_epilogue_rows(const GemmP& p, const f32x16_t 
           const float4 t = *(const float4*)(ebuf + strip_off(r, qq, q_per_row));
           float v[4] = {(t.x + b4.x) * p.acc_scale, (t.y + b4.y) * p.acc_scale, (t.z + b4.z) * p.acc_scale, (t.w + b4.w) * p.acc_scale};
           if constexpr (FILM) {
-            const float4 f = mb + r >= grp_split ? film_hi : film_lo;
+            const float4 f = (parity ? (r & 1) != 0 : mb + r >= grp_split) ? film_hi : film_lo;      // (mb is a multiple of 32)
             v[0] += f.x; v[1] += f.y; v[2] += f.z; v[3] += f.w;
           }
           float r4[4], b4v[4];
@@ -226,6 +229,7 @@ __device__ __forceinline__ void w3_partial_row(const GemmP& p, const f32x16_t (&
 template <typename Tag, int MODE, int LNROWS>
 __global__ __launch_bounds__(512, 2) void gemm_w320_kernel(const GemmP p) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
+  kernarg_touch<sizeof(GemmP)>();
   constexpr int BM = 256, BN = 320, ES = 2, CPR = 8, FM = 2, FN = 5;
   constexpr int A_BYTES = 32768, WJ = 8192, SLOT = A_BYTES + FN * WJ;          // 73728 bytes per slot
   static_assert(Elem<Tag>::ES == 2, "16-bit storage types only");
@@ -471,6 +475,7 @@ __global__ __launch_bounds__(512, 2) void gemm_w320_kernel(const GemmP p) {
 template <typename Tag, int MODE, int LNROWS>
 __global__ __launch_bounds__(512, 2) void gemm_w320h_kernel(const GemmP p) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
+  kernarg_touch<sizeof(GemmP)>();
   constexpr int BM = 128, BN = 320, ES = 2, CPR = 8, FM = 2, FN = 5;
   constexpr int A_BYTES = 16384, WJ = 8192, SLOT = A_BYTES + FN * WJ;          // 57344 bytes per slot
   static_assert(Elem<Tag>::ES == 2, "16-bit storage types only");

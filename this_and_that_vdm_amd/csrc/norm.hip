@@ -140,6 +140,7 @@ __global__ __launch_bounds__(1024) void gn_stats_image_kernel(const char* x0, in
                                                               const float* gamma, const float* beta, float eps,
                                                               float* scale, float* shift, char* y, long ldy, int silu) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
+  kernarg_touch<104>();
   __shared__ float s_mean[GN_GROUPS], s_rstd[GN_GROUPS];
   const int C = c0 + c1, cv = C >> 3;
   const int img = blockIdx.x, tid = threadIdx.x;
@@ -329,6 +330,7 @@ __global__ __launch_bounds__(512) void gn_group_kernel(const char* x0, int c0, c
                                                        char* y, long ldy) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   __shared__ float s_mean[GN_GROUPS], s_rstd[GN_GROUPS];
+  kernarg_touch<88>();
   const int C = c0 + c1, cpg = C / GN_GROUPS;
   const int L = blockIdx.x, xcd = L & 7, t = L >> 3;
   const int slice = t % nslices, img = xcd + 8 * (t / nslices);

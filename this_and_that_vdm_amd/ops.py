@@ -84,7 +84,7 @@ def _rows2d(t: torch.Tensor) -> Tuple[int, int]:
 
 
 def gemm(a0: torch.Tensor, w: torch.Tensor, *, a1: Optional[torch.Tensor] = None, mode: int = 0, conv=None, tconv=None,
-         bias=None, acc_scale: float = 1.0, rowvec=None, rowvec_rows: int = 0, geglu: bool = False, residual=None,
+         bias=None, acc_scale: float = 1.0, rowvec=None, rowvec_rows: int = 0, rowvec_mod: int = 0, geglu: bool = False, residual=None,
          blend=None, alpha: float = 0.0, out: Optional[torch.Tensor] = None, out_f32: bool = False, m: Optional[int] = None,
          out_col_pad: Optional[Tuple[int, int]] = None, ln_fold: int = 0, ln_eps: float = 1e-5,
          out_fp8: bool = False) -> torch.Tensor:
@@ -114,7 +114,10 @@ def gemm(a0: torch.Tensor, w: torch.Tensor, *, a1: Optional[torch.Tensor] = None
     g.m = mm if m is None else m
     g.bias, g.acc_scale = _p(bias), acc_scale
     if rowvec is not None:
-        g.rowvec, g.rowvec_rows, g.ld_rowvec = _p(rowvec), rowvec_rows, rowvec.stride(0)
+        g.rowvec, g.rowvec_rows, g.ld_rowvec, g.rowvec_mod = _p(rowvec), rowvec_rows, rowvec.stride(0), int(rowvec_mod)
+        need_rows = rowvec_mod if rowvec_mod > 0 else (((mm if m is None else m) - 1) // rowvec_rows + 1)
+        if rowvec.dtype != torch.float32 or rowvec.stride(1) != 1 or rowvec.shape[0] < need_rows or rowvec.shape[1] < n:
+            raise RuntimeError(f"gemm: rowvec must be fp32 [>= {need_rows}, >= {n}] with contiguous rows, got {tuple(rowvec.shape)} {rowvec.dtype}")
     g.geglu = int(geglu)
     if residual is not None:
         g.residual, g.ld_res = _p(residual), residual.stride(0)

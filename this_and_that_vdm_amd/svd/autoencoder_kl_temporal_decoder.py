@@ -13,7 +13,10 @@ checkpoint -- and runs the arithmetic on the libttvdm kernels the UNet path alre
 SpatioTemporalResBlock here = the UNet's (layers.py) without a time embedding, AlphaBlender("learned",
 switch_spatial_to_temporal_mix=True).  The mid-block attention has ONE head of 512 channels, outside tt_attention's 64 / 128:
 per frame  scores = tt_gemm(Q, K, fp32 out, scale d^-1/2) -> tt_softmax_rows -> tt_gemm(P, V^T)  (V's bias rides on to_out's
-bias: softmax rows sum to 1).  The encoder side (one image per request, reference :168-188) stays with the caller's module.
+bias: softmax rows sum to 1).  The encoder side (one image + the gesture frames per request, reference :168-188,:652) is not on
+the hot path and stays with the caller's stock module: ``AutoencoderKLTemporalDecoder(encoder=stock_vae)`` /
+``from_pretrained(folder, encoder=stock_vae)`` / ``.with_encoder(stock_vae)`` make ``encode()`` delegate to it, so ONE object
+serves the pipeline's ``vae=`` argument for both directions (test_code/inference.py:169-176 passes one ``vae``).
 """
 from __future__ import annotations
 
@@ -193,17 +196,39 @@ class TemporalDecoder(_Packable):
 
 
 class AutoencoderKLTemporalDecoder(ModelMixin, ConfigMixin):
-    """Decoder half of diffusers' AutoencoderKLTemporalDecoder with the reference call surface: ``decode(z, num_frames)``
-    returns an object with ``.sample``; ``config.scaling_factor``; ``decoder.*`` parameter names.  ``encode`` is not provided."""
+    """diffusers' AutoencoderKLTemporalDecoder with the reference call surface: ``decode(z, num_frames)`` returns an object with
+    ``.sample`` and runs on the libttvdm kernels; ``config.scaling_factor`` / ``force_upcast``; ``decoder.*`` parameter names.
+    ``encode(x)`` is delegated to the caller's stock module given as ``encoder=`` (any object whose ``encode(x)`` returns
+    ``.latent_dist`` -- diffusers' own AutoencoderKLTemporalDecoder); without one it raises.  The stock module is NOT a
+    sub-module (no parameters of it appear in ``state_dict()`` / ``parameters()``), but ``.to()`` / ``.half()`` / ``.float()``
+    reach it too, so the pipeline's force_upcast round trip (reference :556-571: vae.to(fp32) -> encode -> vae.to(fp16)) encodes
+    in fp32 exactly as with the stock class."""
+
+    _config_exclude = ("encoder",)          # a module, not a config entry (save_pretrained writes config.json from self.config)
 
     @register_to_config
     def __init__(self, in_channels: int = 3, out_channels: int = 3, block_out_channels: Tuple[int, ...] = (128, 256, 512, 512),
                  layers_per_block: int = 2, latent_channels: int = 4, sample_size: int = 768, scaling_factor: float = 0.18215,
-                 force_upcast: bool = True):
+                 force_upcast: bool = True, encoder=None):
         super().__init__()
         self.decoder = TemporalDecoder(latent_channels, out_channels, tuple(block_out_channels), layers_per_block)
         self.compute_dtype: Optional[torch.dtype] = None      # None: the parameter dtype if 16-bit, else bf16; float32 = TT_F32 mode
         self._packed_key = None
+        self.__dict__["_stock_encoder"] = None
+        self.with_encoder(encoder)
+
+    def with_encoder(self, encoder):
+        """``encoder``: the caller's stock VAE (or any object with ``encode(x) -> .latent_dist``); None removes it."""
+        if encoder is not None and not callable(getattr(encoder, "encode", None)):
+            raise TypeError("encoder must provide encode(x) returning an object with .latent_dist (diffusers' AutoencoderKLTemporalDecoder)")
+        self.__dict__["_stock_encoder"] = encoder              # outside nn.Module's registry on purpose (see the class docstring)
+        return self
+
+    @classmethod
+    def from_pretrained(cls, pretrained_model_name_or_path, *args, encoder=None, **kwargs):
+        """diffusers-format folder (vae/ of an SVD checkpoint: encoder.* / quant_conv.* entries are ignored) + the stock encoder."""
+        model = super().from_pretrained(pretrained_model_name_or_path, *args, **kwargs)
+        return model.with_encoder(encoder)
 
     def _run_dtype(self) -> torch.dtype:
         if self.compute_dtype is not None:
@@ -229,11 +254,19 @@ class AutoencoderKLTemporalDecoder(ModelMixin, ConfigMixin):
 
     def _apply(self, fn, *a, **k):
         self._packed_key = None
+        stock = self.__dict__.get("_stock_encoder")
+        if isinstance(stock, nn.Module):
+            stock._apply(fn, *a, **k)                          # .to() / .half() / .float() / .cuda() reach the stock encoder too
         return super()._apply(fn, *a, **k)
 
-    def encode(self, *a, **k):
-        raise NotImplementedError("encode one image per request with the stock encoder module (reference :168-188); "
-                                  "this class is the decoder side of the path")
+    def encode(self, x, *a, **k):
+        """Delegated to the stock module given as ``encoder=`` (one image + the gesture frames per request, off the hot path)."""
+        stock = self.__dict__.get("_stock_encoder")
+        if stock is None:
+            raise NotImplementedError("AutoencoderKLTemporalDecoder.encode: no stock encoder attached -- build the model with "
+                                      "encoder=<the diffusers VAE> (or call .with_encoder(vae)); the native kernels cover the decoder side "
+                                      "(decode_latents, reference :257-283), the encoder runs once per request in the caller's module")
+        return stock.encode(x, *a, **k)
 
     @torch.no_grad()
     def decode(self, z: torch.Tensor, num_frames: int = 1, return_dict: bool = True):

@@ -624,10 +624,21 @@ class TemporalBasicTransformerBlock(_Packable):
         wq2, bq2 = fold_layernorm(self.attn2.to_q.weight, None, n2.weight, n2.bias)
         self.q2 = _QProj(zr(wq2), bq2, self.attn2.dim_head)
         self.wo2, self.bo2 = cv(self.attn2.to_out[0].weight), _f32(self.attn2.to_out[0].bias)
-        self.bo12 = (self.bo1 + self.bo2).contiguous()      # rows whose cross-attention context is all zeros (forward)
+        self.__dict__.pop("_crows", None)                   # rows built from the previous pack's bo2 (see _class_rows)
         self.kv = reg.add_kv(self.attn2.to_k, self.attn2.to_v)
         self.ff_in.pack(reg, dtype, norm=self.norm_in)
         self.ff.pack(reg, dtype, norm=self.norm3)
+
+    def _class_rows(self, live, cb: int) -> torch.Tensor:
+        """fp32 [cb, C]: row c = the cross-attention's to_out bias for a residue class whose context is all zeros (its attention
+        output is exactly 0), zeros for a live class (cached per live set: built once, outside graph capture)."""
+        cache = self.__dict__.setdefault("_crows", {})
+        key = (tuple(sorted(live)), cb, self.bo2.data_ptr())
+        rows = cache.get(key)
+        if rows is None:
+            flags = [0.0 if c in live else 1.0 for c in range(cb)]
+            rows = cache[key] = (torch.tensor(flags, dtype=torch.float32, device=self.bo2.device)[:, None] * self.bo2[None, :]).contiguous()
+        return rows
 
     def forward(self, x_spatial, pos_emb, g: Geom, ctx: StepContext, alpha: float, blend_fix=None):
         """x_spatial [M,C]; pos_emb fp32 [F,C].  Returns alpha*x_spatial + (1-alpha)*temporal(x_spatial + pos_emb).
@@ -654,19 +665,11 @@ class TemporalBasicTransformerBlock(_Packable):
             # exactly 0 from the cross-attention, i.e. only to_out's bias.  Query projection, attention and output projection
             # run on the live classes alone, as strided row views t[c::CB] (row stride CB*C; the GEMM and the attention take
             # row strides, the output projection writes in place over its residual).  Exact.  The dead classes' "+ bias" rides
-            # on the self-attention output projection, which therefore runs per class too (bias bo1 + bo2 for the dead ones):
-            # no separate pass over half of the rows.
+            # on the self-attention output projection as a per-class (periodic) row vector: no separate pass over half of the rows.
             cb, off, cc = g.ctx_batches, self.kv[0], self.kv[1]
-            side = _Side()              # the dead classes' projections (disjoint rows of t) next to the live classes' chains
-            with side:
-                for cls in range(cb):
-                    if cls not in live:
-                        tv = t[cls::cb]
-                        ops.gemm(a[cls::cb], self.wo1, bias=self.bo12, residual=tv, out=tv)
-            for cls in live:
-                tv = t[cls::cb]
-                ops.gemm(a[cls::cb], self.wo1, bias=self.bo1, residual=tv, out=tv)
-            a_self = a                  # (kept alive until the join: the side launches read it)
+            # the self-attention's output projection for ALL classes in one launch: the dead classes' extra bias (the cross-attention's
+            # to_out bias bo2) is a periodic row vector -- row r takes class_rows[r % cb] (tt_gemm rowvec_mod; cb = 2: even / odd rows)
+            t = ops.gemm(a, self.wo1, bias=self.bo1, residual=t, rowvec=self._class_rows(live, cb), rowvec_rows=1, rowvec_mod=cb)
             for cls in range(cb):
                 tv = t[cls::cb]
                 if cls in live:
@@ -683,8 +686,6 @@ class TemporalBasicTransformerBlock(_Packable):
                         q = ops.gemm(tv, wq2, bias=bq2, ln_fold=1, ln_eps=self.norm2.eps)
                         ops.attention(q, ctx.k_all[:, off:off + cc], ctx.vt_all[off:off + cc], a, **akw)
                     ops.gemm(a, self.wo2, bias=self.bo2, residual=tv, out=tv)
-            side.join()
-            del a_self
         if blend_fix is not None:
             return self.ff(t, residual=t, blend=xs, alpha=alpha, rowvec=blend_fix, rowvec_rows=g.hw)
         return self.ff(t, residual=t, blend=x_spatial, alpha=alpha)

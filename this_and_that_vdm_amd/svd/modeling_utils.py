@@ -87,7 +87,8 @@ def register_to_config(init):
     def wrapper(self, *args, **kwargs):
         bound = sig.bind(self, *args, **kwargs)
         bound.apply_defaults()
-        cfg = {k: v for k, v in bound.arguments.items() if k != "self"}
+        skip = ("self",) + tuple(getattr(type(self), "_config_exclude", ()))      # run-time objects are not config entries
+        cfg = {k: v for k, v in bound.arguments.items() if k not in skip}
         init(self, *args, **kwargs)
         cfg["_class_name"] = type(self).__name__
         self._internal_dict = FrozenDict(cfg)

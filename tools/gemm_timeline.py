@@ -28,8 +28,10 @@ def main():
     raw.tt_debug_timeline(buf.ctypes.data_as(C.c_void_p), C.c_int(8 * 8192))
     t = buf.reshape(8192, 8)
     nblk = int((t[:, 0] > 0).sum())
+    extra = t[:nblk, 6:8].astype(np.float64)       # inside the prologue: 6 = addresses done (before the first DMA / the residual batch), 7 = first tile requested
     t = t[:nblk, :6].astype(np.float64)
     t0 = t[:, 0].min()
+    extra = (extra - t0) * 0.01
     t = (t - t0) * 0.01      # 100 MHz -> us
     names = ["start", "prologue done", "tile0 landed", "mainloop done", "ring free", "stores done"]
     print(f"M={m} N={n} K={k} cfg{cfg} res={res}: {nblk} blocks; kernel span {t[:, 5].max():.2f} us")
@@ -39,6 +41,10 @@ def main():
         print(f"  block#{q:4d} (by start): " + " | ".join(f"{names[i]} {t[b, i]:6.2f}" for i in range(6)))
     d = np.diff(t, axis=1)
     print("  mean phase us: " + " | ".join(f"{names[i+1]} +{d[:, i].mean():.2f}" for i in range(5)))
+    if (extra[:, 0] > 0).all():
+        print(f"  inside the prologue (mean us after start): arguments + tile mapping + address set-up {np.mean(extra[:, 0] - t[:, 0]):.2f}" +
+              (f" | first tile requested {np.mean(extra[:, 1] - t[:, 0]):.2f}" if (extra[:, 1] > 0).all() else "") +
+              f" | residual batch requested {np.mean(t[:, 1] - t[:, 0]):.2f}")
     print(f"  start times: min {t[:,0].min():.2f} median {np.median(t[:,0]):.2f} max {t[:,0].max():.2f}")
 
 if __name__ == "__main__":
