@@ -101,8 +101,21 @@ typedef struct TtGemmArgs {
    * cross-attention's to_out bias, transformer_temporal.py:342-365 via TemporalBasicTransformerBlock) in ONE launch instead of one
    * launch per class on strided row views.  0: the plain form above. */
   int32_t rowvec_mod;
+  /* ABI 8.  stats_out != NULL: beside its output the kernel writes, per row tile of R = tt_gemm_stats_rows(args) output rows and per
+   * column, the sum and the sum of squares of the values it STORES (after rounding to the storage type):
+   *     stats_out[(t * 2 + 0) * n + c] = sum_{r in tile t} out[r][c]        stats_out[(t * 2 + 1) * n + c] = sum of squares
+   * fp32, [ceil(m / R)][2][n] floats, no atomics (fixed summation order: bit-reproducible).  This is the producer half of GroupNorm
+   * (nn.GroupNorm(32) in ResnetBlock2D / TemporalResnetBlock / TransformerSpatioTemporalModel.norm -- unet_3d_blocks.py:1891-2316,
+   * transformer_temporal.py:323-326): the tensor a GroupNorm reads is the output of a conv / Linear launch, whose epilogue has every
+   * value in registers; tt_groupnorm_tiles turns the tile sums into the normalised tensor in ONE pass over it, without a
+   * statistics pass.  Only routes and shapes for which tt_gemm_stats_rows(args) > 0 (TT_EUNSUPPORTED otherwise). */
+  float* stats_out;
 } TtGemmArgs;
 int tt_gemm(const TtGemmArgs* args, tt_stream_t stream);
+/* rows per statistics tile if tt_gemm can serve `args` with stats_out (the row height of the tile kernel the planner picks; m must be
+ * a multiple of it); 0: this problem's route has no statistics epilogue (split-K, GEGLU, fp8 / fp32 / transposed outputs, the
+ * persistent kernels) -- leave stats_out NULL.  Host-only; call with ws / ws_bytes set as for tt_gemm (the plan depends on them). */
+int32_t tt_gemm_stats_rows(const TtGemmArgs* args);
 /* which tile configuration tt_gemm will use for this problem: cfg[0..6] = BM, BN, BK, ring stages, waves along M,
  * waves along N, split-K factor.  Lets a profiler name the kernel instance
  * (gemm_kernel<dtype, BM, BN, BK, stages, wavesM, wavesN, mode>) a launch maps to.  Host-only, no launch. */
@@ -223,6 +236,15 @@ int tt_groupnorm_stats(const void* x0, int32_t c0, const void* x1, int32_t c1, i
                        float* scale, float* shift, void* ws, size_t ws_bytes, int32_t dtype, tt_stream_t stream);
 /* y[n,p,0:c0+c1] = act(x*scale+shift), act = SiLU if silu else identity; y has row stride ldy (>= c0+c1,
  * extra columns untouched). */
+/* GroupNorm(32) (+SiLU) of x [nseg * seg_rows, c] from the tile sums its producer left (TtGemmArgs.stats_out, stat_rows = the
+ * tt_gemm_stats_rows of that launch): ONE pass over x, one launch, for per-image statistics (seg_rows = h*w) and for the cross-frame
+ * statistics of TemporalResnetBlock (seg_rows = frames*h*w) alike.  seg_rows must be a multiple of stat_rows (a segment is a whole
+ * number of statistics tiles): tt_groupnorm_tiles_supported.  Replaces the statistics pass of tt_groupnorm_small / tt_groupnorm_stats
+ * for nn.GroupNorm sites whose input is the direct output of one tt_gemm launch (unet_3d_blocks.py:1891-2316). */
+int tt_groupnorm_tiles_supported(int32_t seg_rows, int32_t c, int32_t stat_rows, int32_t dtype);
+int tt_groupnorm_tiles(const void* x, int32_t c, const float* stats, int32_t stat_rows, int32_t nseg, int32_t seg_rows,
+                       const float* gamma, const float* beta, float eps, int32_t silu, void* y, int64_t ldy, int32_t dtype,
+                       tt_stream_t stream);
 int tt_groupnorm_apply(const void* x0, int32_t c0, const void* x1, int32_t c1, int32_t nimg, int32_t hw,
                        const float* scale, const float* shift, int32_t silu, void* y, int64_t ldy,
                        int32_t dtype, tt_stream_t stream);

@@ -915,3 +915,75 @@ def test_gemm_periodic_row_vector(ops, dtype, m, n, k, rows_per, mod):
         torch.testing.assert_close(out.float(), two.float(), rtol=tol["rtol"], atol=tol["atol"])
     with pytest.raises(RuntimeError):
         ops.gemm(ad, wd, bias=bd, rowvec=rd[:1], rowvec_rows=rows_per, rowvec_mod=mod)          # fewer vectors than the period
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("case", ["w320_conv", "w320_linear_res", "w320_tconv_blend", "w320h_conv", "tiled_linear", "tiled_tconv", "tiled_small"])
+def test_gemm_output_statistics_and_groupnorm_from_tiles(ops, dtype, case):
+    """TtGemmArgs.stats_out: per (row tile, column) sum / sum of squares of the STORED output, on every route that has the epilogue
+    (256 x 320 and 128 x 320 big tiles, the tiled template), against sums over the stored tensor; then tt_groupnorm_tiles (one pass
+    from those sums) against torch group_norm on the stored tensor, per-image and cross-frame (a video = `frames` images), and against
+    the statistics-pass kernels (ops.groupnorm with TT_GN_TILES off) within storage rounding.  Launches without statistics must give
+    the same output bit for bit."""
+    frames = 4
+    g = dict(w320_conv=dict(nimg=28, h=32, w=56, cin=64, n=320, mode=1), w320_linear_res=dict(rows=50176, k=128, n=320, mode=0, res=True),
+             w320_tconv_blend=dict(nimg=28, h=32, w=56, cin=64, n=320, mode=2, blend=True), w320h_conv=dict(nimg=28, h=16, w=28, cin=64, n=640, mode=1),
+             tiled_linear=dict(rows=3584, k=256, n=640, mode=0, res=True), tiled_tconv=dict(nimg=8, h=16, w=28, cin=128, n=640, mode=2),
+             tiled_small=dict(rows=1024, k=64, n=96, mode=0))[case]
+    if dtype == torch.float32 and case.startswith("w320"):
+        pytest.skip("the big-tile kernels serve 16-bit storage")
+    mode, n = g["mode"], g["n"]
+    if mode == 0:
+        rows, k = g["rows"], g["k"]
+        hw = rows // 28 if rows % 28 == 0 else rows // 8
+    else:
+        hw, k = g["h"] * g["w"], g["cin"]
+        rows = g["nimg"] * hw
+    taps = {0: 1, 1: 9, 2: 3}[mode]
+    a = rnd(rows, k, dtype=dtype, seed=1).cuda()
+    w = rnd(n, taps * k, dtype=dtype, seed=2, scale=(taps * k) ** -0.5).cuda()
+    bias = (rnd(n, dtype=torch.float32, seed=3) + 0.5).cuda()
+    kw = dict(bias=bias, mode=mode)
+    if mode == 1:
+        kw["conv"] = (g["nimg"], g["h"], g["w"], g["h"], g["w"], 1, 0)
+    if mode == 2:
+        kw["tconv"] = (frames, hw)
+    res = rnd(rows, n, dtype=dtype, seed=5).cuda()
+    if g.get("res") or g.get("blend"):
+        kw["residual"] = res
+    if g.get("blend"):
+        kw.update(blend=res, alpha=0.3)
+    seg = frames * hw                                      # (the cross-frame segment: a multiple of hw)
+    plain = ops.gemm(a, w, **kw)
+    out = ops.gemm(a, w, stats=seg, **kw)
+    assert torch.equal(out, plain), "the statistics epilogue must not change the output"
+    st = getattr(out, "_tt_stats", None)
+    assert st is not None, f"{case}: route without statistics epilogue"
+    sbuf, r = st
+    if case.startswith("w320h"):
+        assert r == 128
+    elif case.startswith("w320"):
+        assert r == 256
+    x = out.float()
+    want = torch.stack([x.view(rows // r, r, n).sum(1), (x * x).view(rows // r, r, n).sum(1)], 1)
+    torch.testing.assert_close(sbuf, want, rtol=2e-5, atol=2e-4)
+    again = ops.gemm(a, w, stats=seg, **kw)
+    assert torch.equal(again._tt_stats[0], sbuf), "tile sums must be bit-reproducible"
+    # GroupNorm from the tile sums, per image (seg = hw rows) and across frames (seg = frames * hw rows)
+    gamma, beta = (rnd(n, dtype=torch.float32, seed=6) * 0.2 + 1).cuda(), (rnd(n, dtype=torch.float32, seed=7) * 0.3).cuda()
+    nimg = rows // hw
+    for fpg in (1, frames):
+        seg = fpg * hw
+        if seg % r:
+            continue
+        y = ops.groupnorm(out, None, nimg, hw, fpg, gamma, beta, 1e-5, True)
+        ref = F.silu(F.group_norm(x.view(nimg // fpg, seg, n).permute(0, 2, 1), 32, gamma, beta, 1e-5)).permute(0, 2, 1).reshape(rows, n)
+        close(y, ref.cpu(), dtype, scale=2.0)
+        del out._tt_stats                                   # the statistics-pass kernels on the same tensor
+        y_old = ops.groupnorm(out, None, nimg, hw, fpg, gamma, beta, 1e-5, True)
+        out._tt_stats = st
+        tol = TOL[dtype]
+        torch.testing.assert_close(y.float(), y_old.float(), rtol=tol["rtol"], atol=tol["atol"])
+    # an in-place overwrite drops the stale sums
+    ops.gemm(a, w, out=out, **kw)
+    assert not hasattr(out, "_tt_stats")

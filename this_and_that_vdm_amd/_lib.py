@@ -29,6 +29,7 @@ class TtGemmArgs(C.Structure):
         ("ws", C.c_void_p), ("ws_bytes", C.c_int64),
         ("ln_fold", C.c_int32), ("ln_eps", C.c_float), ("out_fp8", C.c_int32),
         ("rowvec_mod", C.c_int32),          # ABI 7: periodic row vector
+        ("stats_out", C.c_void_p),          # ABI 8: per (row tile, column) sum / sum of squares of the stored output
     ]
 
 
@@ -81,6 +82,9 @@ SIGNATURES = {
     "tt_groupnorm_small": (C.c_int, [_vp, _i32, _vp, _i32, _i32, _i32, _vp, _vp, _f32, _i32, _vp, _i64, _i32, _vp]),
     "tt_groupnorm_stats": (C.c_int, [_vp, _i32, _vp, _i32, _i32, _i32, _i32, _vp, _vp, _f32, _vp, _vp, _vp, _sz, _i32, _vp]),
     "tt_groupnorm_apply": (C.c_int, [_vp, _i32, _vp, _i32, _i32, _i32, _vp, _vp, _i32, _vp, _i64, _i32, _vp]),
+    "tt_groupnorm_tiles_supported": (C.c_int, [_i32, _i32, _i32, _i32]),
+    "tt_groupnorm_tiles": (C.c_int, [_vp, _i32, _vp, _i32, _i32, _i32, _vp, _vp, _f32, _i32, _vp, _i64, _i32, _vp]),
+    "tt_gemm_stats_rows": (C.c_int32, [C.POINTER(TtGemmArgs)]),
     "tt_layernorm": (C.c_int, [_vp, _i64, _i32, _i32, _vp, _vp, _f32, _vp, _i32, _i32, _vp, _vp, _i64, _i32, _vp]),
     "tt_small_linear": (C.c_int, [_vp, _i64, _i32, _i32, _vp, _i64, _i32, _vp, _i32, _i32, _i32, _vp, _i64, _i32, _vp]),
     "tt_timestep_embedding": (C.c_int, [_vp, _i32, _i32, _vp, _i64, _vp]),
@@ -123,7 +127,7 @@ def load():
     for name, (res, args) in SIGNATURES.items():
         fn = getattr(lib, name)          # AttributeError here == ABI mismatch with include/ttvdm.h
         fn.restype, fn.argtypes = res, args
-    if lib.tt_abi_version() != 7:
+    if lib.tt_abi_version() != 8:
         raise RuntimeError("libttvdm.so ABI version mismatch")
     _lib = lib
     return lib

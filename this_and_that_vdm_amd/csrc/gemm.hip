@@ -310,6 +310,21 @@ extern "C" int tt_gemm_plan(const TtGemmArgs* a, int32_t cfg[7]) {
   return TT_OK;
 }
 
+// rows per statistics tile of the route tt_gemm takes (0: no statistics epilogue on it); see include/ttvdm.h
+extern "C" int32_t tt_gemm_stats_rows(const TtGemmArgs* a) {
+  if (!a || a->m <= 0 || a->n <= 0) return 0;
+  if (a->geglu || a->out_fp8 || a->out_f32 || a->out_col_hw > 0 || a->ln_fold == 2) return 0;
+  if (pp_ok(a) || pp_split_rows(a) || sq320_ok(a)) return 0;
+  // the statistics variants exist for the straight-line epilogues: bias / scale / row vector of >= 32-row groups (or the even / odd
+  // form) / residual / a blend with the residual itself -- not for the in-pass operand loads (gemm_kernel.h, `inpass`)
+  if (a->blend && !(a->blend == a->residual && a->ld_blend == a->ld_res)) return 0;
+  if (a->rowvec && a->rowvec_rows < 32 && !(a->rowvec_rows == 1 && a->rowvec_mod == 2)) return 0;
+  int32_t cfg[7];
+  if (tt_gemm_plan(a, cfg) != TT_OK || cfg[6] != 1) return 0;          // split-K: the reduction kernel has no statistics
+  if (cfg[0] > 128 && cfg[1] != 320 && a->residual) return 0;         // 256-row tiles of the tiled template read the residual in-pass
+  return a->m % cfg[0] == 0 ? cfg[0] : 0;
+}
+
 extern "C" size_t tt_gemm_ws_bytes(const TtGemmArgs* a) {
   if (!a || a->m <= 0 || a->n <= 0) return 0;
   if (pp_ok(a)) return 0;
@@ -337,6 +352,8 @@ extern "C" int tt_gemm(const TtGemmArgs* a, tt_stream_t stream) {
   if (a->geglu && ((a->n & 15) || a->residual || a->blend || a->rowvec || a->out_f32 || a->out_col_hw))
     TT_FAIL(TT_EINVAL, "tt_gemm: geglu needs n %% 16 == 0 and no other epilogue terms");
   if (a->rowvec && a->rowvec_rows <= 0) TT_FAIL(TT_EINVAL, "tt_gemm: rowvec_rows");
+  if (a->stats_out && tt_gemm_stats_rows(a) == 0)
+    TT_FAIL(TT_EUNSUPPORTED, "tt_gemm: stats_out on a route without a statistics epilogue (tt_gemm_stats_rows(args) == 0)");
   if (a->rowvec_mod < 0 || (a->rowvec_mod > 0 && !a->rowvec)) TT_FAIL(TT_EINVAL, "tt_gemm: rowvec_mod %d (>= 0, needs rowvec)", a->rowvec_mod);
   if (a->ln_fold < 0 || a->ln_fold > 2) TT_FAIL(TT_EINVAL, "tt_gemm: ln_fold %d (0 none, 1 rows of A, 2 rows of W)", a->ln_fold);
   if (a->ln_fold && (a->mode != 0 || a->k1 != 0 || !(a->ln_eps > 0.f)))
@@ -357,7 +374,7 @@ extern "C" int tt_gemm(const TtGemmArgs* a, tt_stream_t stream) {
   const int es = a->dtype == TT_F32 ? 4 : 2;         // bytes per stored element
   p.out = (char*)a->out; p.ldo = a->ldo; p.out_f32 = a->dtype == TT_F32 ? 0 : a->out_f32;   // TT_F32 stores fp32 anyway
   p.out_col_hw = a->out_col_hw; p.out_col_hwp = a->out_col_hwp;
-  p.ln_fold = a->ln_fold; p.ln_eps = a->ln_eps; p.out_fp8 = a->out_fp8;
+  p.ln_fold = a->ln_fold; p.ln_eps = a->ln_eps; p.out_fp8 = a->out_fp8; p.stats = a->stats_out;
   if (p.mode == 1) {
     if (p.nimg <= 0 || p.hin <= 0 || p.win <= 0 || p.hout <= 0 || p.wout <= 0 || p.stride < 1)
       TT_FAIL(TT_EINVAL, "tt_gemm: conv geometry");

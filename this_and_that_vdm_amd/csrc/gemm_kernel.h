@@ -50,6 +50,7 @@ struct GemmP {
   float* ws;                        // [splitk][m][n] fp32 partial sums
   int ln_fold; float ln_eps;        // fused LayerNorm of the A rows (1) / W rows (2): see gemm_kernel, MODE 3 / 4
   int out_fp8;                      // store e4m3 bytes (operands of the fp8 attention path) instead of 16-bit values
+  float* stats;                     // != NULL: per (row tile, column) sum and sum of squares of the stored output (TtGemmArgs.stats_out)
   // launch-uniform divisors of the tiled template as multiply-shift pairs (fill_fastdivs, called by launch_cfg)
   FastDiv fd_splitk, fd_per_group, fd_group_m, fd_last_rows, fd_per_tap, fd_hwo, fd_wout, fd_hw, fd_frames, fd_rv_rows, fd_rv_mod;
 };
@@ -63,6 +64,28 @@ __device__ __forceinline__ unsigned pack4_fp8(const float* v) {
 }
 __device__ __forceinline__ void st32(__amdgpu_buffer_rsrc_t r, int off, unsigned a) {
   __builtin_amdgcn_raw_buffer_store_b32(a, r, off, 0, 0);
+}
+
+// ---- GroupNorm statistics of the OUTPUT, gathered beside the epilogue (GemmP.stats).  The epilogue passes a 32-row x 64 (32)
+// column chunk through the wave's LDS strip; with statistics on, every lane writes the values it STORES (rounded to the storage type,
+// as fp32) back into the strip slot it just read, and after the chunk's passes lane c adds up column c of the strip -- 32 rows, fixed
+// order, two live registers (a version that kept 8 running sums per lane through the passes spilled 10-17 registers next to the 160
+// accumulators of gemm_w320).  The wave's column sums go to its staging rows in LDS (plain store for the wave's first fragment row,
+// read-add-store by the same lane for the following ones); the tile-level step then adds the waves of one tile column in a fixed order:
+//   stats[(tile_m * 2 + 0) * n + col] = sum,  stats[(tile_m * 2 + 1) * n + col] = sum of squares     (fp32, one row tile = BM rows)
+// No atomics: graph replays and eager launches stay bit-identical.
+__device__ __forceinline__ void colstat_strip(const char* ebuf, int q_per_row, int lane, float* srow_sum, float* srow_sq, bool first) {
+  if (lane < q_per_row * 4) {                                // one lane per column of the chunk
+    const int quad = lane >> 2, e4 = (lane & 3) * 4;
+    float a = 0.f, b = 0.f;
+#pragma unroll 8
+    for (int r = 0; r < 32; ++r) {
+      const float x = *(const float*)(ebuf + r * 256 + ((quad ^ (r & (q_per_row - 1))) << 4) + e4);      // strip_off(r, quad, q_per_row)
+      a += x; b = fmaf(x, x, b);
+    }
+    if (!first) { a += srow_sum[lane]; b += srow_sq[lane]; }
+    srow_sum[lane] = a; srow_sq[lane] = b;
+  }
 }
 
 // ---- running sum and sum of squares of one 16-byte MFMA operand chunk (fused LayerNorm statistics).  16-bit storage: two
@@ -620,6 +643,7 @@ void gemm_kernel(const GemmP p) {
   // l31 of fragment j publishes 1/sigma of output column j*32 + l31 in a wave-private LDS array behind the ring; the
   // epilogue multiplies by it where a lane holds four consecutive columns.
   constexpr int CS_OFF = NST * STAGE;                  // MODE 4 only: WGM*WGN KiB more dynamic LDS (launch_mode)
+  constexpr int STAT_OFF = NST * STAGE + (KMODE == 4 ? WGM * WGN * 1024 : 0);    // GemmP.stats: 8 * BN * WGM bytes more (launch_mode)
   if constexpr (LN != 0) {
     const float inv_k = 1.0f / (float)p.k0;
     float rs[NLN];
@@ -677,8 +701,10 @@ void gemm_kernel(const GemmP p) {
       //          128-VGPR budget has no room for the preload -- the residual.  A load issued after a store waits for
       //          that store (in-order vmcnt), so each batch loads first and stores last; the planner keeps such
       //          epilogues off the 256-row tiles.
-      auto run = [&](auto film_tag, auto inpass_tag, auto out8_tag) {
+      auto run = [&](auto film_tag, auto inpass_tag, auto out8_tag, auto stats_tag) {
         constexpr bool FILM = decltype(film_tag)::value, INPASS = decltype(inpass_tag)::value, OUT8 = decltype(out8_tag)::value;
+        // GemmP.stats, compile-time like the operand variants (a run-time `if` inside the pass loops breaks the straight-line code)
+        constexpr bool STATS = decltype(stats_tag)::value;
         const __amdgpu_buffer_rsrc_t r_rv = make_rsrc(p.rowvec, (FILM || INPASS) ? p.rowvec_bytes : 0);
         const __amdgpu_buffer_rsrc_t r_bl = make_rsrc(p.blend, INPASS ? p.blend_bytes : 0);
         const __amdgpu_buffer_rsrc_t r_res = make_rsrc(p.residual, (INPASS && !EARLY_RES) ? p.res_bytes : 0);
@@ -687,12 +713,14 @@ void gemm_kernel(const GemmP p) {
         // two-vector path below with the row's parity as the selector
         const bool parity = FILM && p.rowvec_mod == 2 && rv_rows == 1;
         auto wrap = [&](int g) { return p.rowvec_mod > 0 ? g - fdiv(g, p.fd_rv_mod) * p.rowvec_mod : g; };
+        float* sstage = (float*)(smem + STAT_OFF) + wid * (2 * WTN);      // staging rows behind the ring (launch_mode adds the bytes)
 #pragma unroll
         for (int i = 0; i < FM; ++i) {
           const int mb = m0 + wr * WTM + i * 32;
           const int grp_raw = fdiv(mb, p.fd_rv_rows);    // row group of the fragment's first row (uniform)
           const int grp0 = parity ? 0 : wrap(grp_raw), grp1 = parity ? 1 : wrap(grp_raw + 1);
           const int grp_split = parity ? mb : (grp_raw + 1) * rv_rows;    // first row of the next group (parity: see the selector)
+          const int sel_split = parity ? 0x7fffffff : grp_split, sel_odd = parity ? 1 : 0;
 #pragma unroll
           for (int jc = 0; jc < FN; jc += 2) {
             const int nfr = (jc + 1 < FN) ? 2 : 1;       // fragments in this chunk (compile-time after unrolling)
@@ -754,7 +782,7 @@ void gemm_kernel(const GemmP p) {
                     const quad_t rq = rqv[k];
                     quad_t bq = rq;
                     if constexpr (FILM) {
-                      const float4 f = (parity ? (gm & 1) != 0 : gm >= grp_split) ? film_hi : film_lo;
+                      const float4 f = ((gm >= sel_split) | ((gm & sel_odd) != 0)) ? film_hi : film_lo;     // branch-free (see gemm_w320.hip)
                       v[0] += f.x; v[1] += f.y; v[2] += f.z; v[3] += f.w;
                     }
                     if constexpr (INPASS) {
@@ -767,21 +795,50 @@ void gemm_kernel(const GemmP p) {
 #pragma unroll
                     for (int e = 0; e < 4; ++e) v[e] = alpha * b4v[e] + one_m_alpha * (v[e] + r4[e]);
                     if constexpr (OUT8) st32(r_out, ok ? (int)((long)gm * p.ldo + gn) : kInv, pack4_fp8(v));
-                    else stq<Tag>(r_out, ok ? (int)(((long)gm * p.ldo + gn) * ES) : kInv, v);
+                    else {
+                      const quad_t packed = f32_to_quad<Tag>(v);
+                      if constexpr (ES == 2) st64(r_out, ok ? (int)(((long)gm * p.ldo + gn) * ES) : kInv, packed.x, packed.y);
+                      else stq<Tag>(r_out, ok ? (int)(((long)gm * p.ldo + gn) * ES) : kInv, v);
+                      if constexpr (STATS) {               // (rows >= m never occur: the host grants stats only for m % BM == 0)
+                        float sv[4];
+                        quad_to_f32<Tag>(packed, sv);
+                        *(float4*)(ebuf + strip_off(r, qq, q_per_row)) = make_float4(sv[0], sv[1], sv[2], sv[3]);
+                      }
+                    }
                   }
                 }
               }
             }
+            if constexpr (STATS) colstat_strip(ebuf, q_per_row, lane, sstage + jc * 32, sstage + WTN + jc * 32, i == 0);
           }
         }
       };
       const bool inpass = (p.blend && !blend_is_res) || (p.rowvec && p.rowvec_rows < 32 && !(p.rowvec_mod == 2 && p.rowvec_rows == 1)) ||
                           (!EARLY_RES && p.residual);
-      if (inpass) run(std::false_type{}, std::true_type{}, std::false_type{});
-      else if (p.rowvec) run(std::true_type{}, std::false_type{}, std::false_type{});
+      constexpr std::false_type no{};
+      constexpr std::true_type yes{};
+      if (inpass) run(no, yes, no, no);                      // (never with statistics: tt_gemm_stats_rows)
+      else if (p.rowvec) { if (p.stats) run(yes, no, no, yes); else run(yes, no, no, no); }
       else if (MODE == 0 && ES == 2 && p.out_fp8) {          // Q | K and V^T of the fp8 attention path (linear, no residual)
-        if constexpr (MODE == 0 && ES == 2) run(std::false_type{}, std::false_type{}, std::true_type{});
-      } else run(std::false_type{}, std::false_type{}, std::false_type{});
+        if constexpr (MODE == 0 && ES == 2) run(no, no, yes, no);
+      } else { if (p.stats) run(no, no, no, yes); else run(no, no, no, no); }
+      if (p.stats) {                                       // the waves of one tile column, wave rows in order
+        __syncthreads();
+        const float* st0 = (const float*)(smem + STAT_OFF);
+        for (int c = tid; c < BN; c += NT) {
+          const int wcc = c / WTN, col = c - wcc * WTN;
+          float a = 0.f, b = 0.f;
+#pragma unroll
+          for (int w = 0; w < WGM; ++w) {
+            const float* row = st0 + (w * WGN + wcc) * (2 * WTN);
+            a += row[col]; b += row[WTN + col];
+          }
+          if (n0 + c < p.n) {
+            p.stats[((long)tile_m * 2) * p.n + n0 + c] = a;
+            p.stats[((long)tile_m * 2 + 1) * p.n + n0 + c] = b;
+          }
+        }
+      }
     } else {
       // GEGLU: value/gate pairs are lane-local (regs g=0/2 value, g=1/3 gate); gelu in registers, then the 16
       // output columns of each fragment go through the strip: 2 fragments -> 32 output columns = 64 bytes per row.
@@ -1050,12 +1107,13 @@ void launch_mode(const GemmP& p, hipStream_t st) {
   constexpr int NT_ = 64 * WGM * WGN, CPR_ = BK / Elem<Tag>::EPC;
   constexpr size_t lds = (size_t)NST * (((BM * CPR_ + NT_ - 1) / NT_) + ((BN * CPR_ + NT_ - 1) / NT_)) * NT_ * 16
                          + (MODE == 4 ? WGM * WGN * 1024 : 0);          // + the per-wave column-scale arrays
-  static_assert(lds <= 160 * 1024, "LDS ring exceeds 160 KiB");
+  static_assert(lds + (size_t)WGM * WGN * 2 * (BN / WGN) * sizeof(float) <= 160 * 1024, "LDS ring (+ the statistics staging rows) exceeds 160 KiB");
   static_assert(MODE != 4 || BN / WGN <= 256, "column-scale array: 1 KiB per wave");
+  constexpr size_t stat_lds = (size_t)WGM * WGN * 2 * (BN / WGN) * sizeof(float);        // per wave: sum and sum-of-squares rows of its columns
   static unsigned long long attr_done = 0;     // per kernel instance, one bit per device (see tt_lds_opt_in)
-  tt_lds_opt_in((const void*)gemm_kernel<Tag, BM, BN, BK, NST, WGM, WGN, MODE>, (int)lds, &attr_done);
+  tt_lds_opt_in((const void*)gemm_kernel<Tag, BM, BN, BK, NST, WGM, WGN, MODE>, (int)(lds + stat_lds), &attr_done);
   hipLaunchKernelGGL((gemm_kernel<Tag, BM, BN, BK, NST, WGM, WGN, MODE>), dim3(p.tiles_m * p.tiles_n * p.splitk),
-                     dim3(64 * WGM * WGN), lds, st, p);
+                     dim3(64 * WGM * WGN), p.stats ? lds + stat_lds : lds, st, p);
   if (p.splitk > 1) {
     long blocks = ((long)p.m * (p.n >> 2) + 255) / 256;
     if (blocks > 2048) blocks = 2048;

@@ -50,12 +50,12 @@ template <int N> __device__ __forceinline__ void w3_wait_vm() { asm volatile("s_
 // XCHG (gemm_w320h_kernel): the wave holds only one K half of the tile.  Per chunk it first writes the fragments of the row it
 // gives away (`give`) lane-linearly into `xbuf`; after a workgroup barrier the partner's partial sums of THIS row are read from `pbuf`
 // and added on the way into the strip (the accumulator tuples are never updated element-wise: hipcc spills them if they are).
-template <typename Tag, int NI, bool FILM, bool RES, bool BLEND, bool XCHG>
+template <typename Tag, int NI, bool FILM, bool RES, bool BLEND, bool XCHG, bool STATS>
 __device__ __forceinline__ void w3_epilogue_rows(const GemmP& p, const f32x16_t (*accs)[5], const float* rss, char* ebuf, int mb0, int ncol0,
-                                                 int lane, float alpha, const f32x16_t (&give)[5], char* xbuf, const char* pbuf) {
+                                                 int lane, float alpha, const f32x16_t (&give)[5], char* xbuf, const char* pbuf, float* sstage) {
   typedef typename Elem<Tag>::quad_t quad_t;
   constexpr int ES = 2;
-  const int l31 = lane & 31, hi = lane >> 5;
+  const int hi = lane >> 5;
   const __amdgpu_buffer_rsrc_t r_bias = make_rsrc(p.bias, p.bias_bytes);
   const __amdgpu_buffer_rsrc_t r_out = make_rsrc(p.out, p.out_bytes);
   const __amdgpu_buffer_rsrc_t r_rv = make_rsrc(p.rowvec, FILM ? p.rowvec_bytes : 0);
@@ -63,6 +63,9 @@ __device__ __forceinline__ void w3_epilogue_rows(const GemmP& p, const f32x16_t 
   const __amdgpu_buffer_rsrc_t r_bl = make_rsrc(p.blend, BLEND ? p.blend_bytes : 0);
   const float one_m_alpha = 1.0f - alpha;
   const int rv_rows = FILM ? p.rowvec_rows : 1;
+  // STATS (GemmP.stats): column sums of the stored values (gemm_kernel.h, colstat_strip).  Compile-time like the operand variants: a
+  // uniform run-time `if` inside the pass loops turns the straight-line epilogue into basic blocks, and hipcc then drains vmcnt
+  // between them (measured: +4 us on a 23 us launch with the run-time form)
   const bool parity = FILM && p.rowvec_mod == 2 && rv_rows == 1;             // even / odd rows: two vectors, the row's parity selects
   auto wrap = [&](int g) { return p.rowvec_mod > 0 ? g % p.rowvec_mod : g; };   // periodic row vector (uniform, once per fragment row)
   auto strip_off = [](int row, int quad, int nq) { return row * 256 + ((quad ^ (row & (nq - 1))) << 4); };
@@ -71,13 +74,19 @@ __device__ __forceinline__ void w3_epilogue_rows(const GemmP& p, const f32x16_t 
   const f32x16_t (&acc)[5] = accs[i];
   const float rs = rss[i];
   const int mb = mb0 + i * 32;
+  // the strip addresses of the transposition are recomputed per fragment row (a few VALU): kept live from row 0 to row 1 they were the
+  // registers hipcc spilled once the statistics code was added (3-8 per lane, reloaded behind a vmcnt(0))
+  int l31 = lane & 31;
+  asm volatile("" : "+v"(l31));
   const int grp_raw = mb / rv_rows, grp_split = (grp_raw + 1) * rv_rows;    // row group of the fragment's first row, first row of the next
   const int grp0 = parity ? 0 : wrap(grp_raw), grp1 = parity ? 1 : wrap(grp_raw + 1);
+  const int sel_split = parity ? 0x7fffffff : grp_split, sel_odd = parity ? 1 : 0;
   // Residual only (the common case: to_out, FF2, proj_out, conv2 + shortcut): ALL 24 loads of the fragment row are issued before
   // the first chunk is processed.  Batch by batch (loads, wait, stores, next loads behind those stores: in-order vmcnt) a wave pays
   // one memory round trip per batch -- 12 per tile, the whole epilogue of a K = 320 problem; up front it pays one (two) per fragment row.
   constexpr bool PRELOAD = RES && !BLEND;
-  constexpr int NPRE = NI == 2 ? 2 : 3;                      // chunks loaded up front: what the registers next to the live accumulators hold without spilling
+  // chunks loaded up front: what the registers next to the live accumulators hold without spilling (one chunk fewer with the statistics code)
+  constexpr int NPRE = (NI == 2 ? 2 : 3) - (STATS ? 1 : 0);
   quad_t pre[PRELOAD ? NPRE : 1][PRELOAD ? 8 : 1];
   if constexpr (PRELOAD) {
 #pragma unroll
@@ -154,7 +163,9 @@ __device__ __forceinline__ void w3_epilogue_rows(const GemmP& p, const f32x16_t 
           const float4 t = *(const float4*)(ebuf + strip_off(r, qq, q_per_row));
           float v[4] = {(t.x + b4.x) * p.acc_scale, (t.y + b4.y) * p.acc_scale, (t.z + b4.z) * p.acc_scale, (t.w + b4.w) * p.acc_scale};
           if constexpr (FILM) {
-            const float4 f = (parity ? (r & 1) != 0 : mb + r >= grp_split) ? film_hi : film_lo;      // (mb is a multiple of 32)
+            // branch-free selector (a `parity ? .. : ..` here became a uniform BRANCH per pass and broke the straight-line code):
+            // groups of >= 32 rows: rows from grp_split on take the next group's vector; even / odd form: odd rows (mb is a multiple of 32)
+            const float4 f = ((mb + r >= sel_split) | ((r & sel_odd) != 0)) ? film_hi : film_lo;
             v[0] += f.x; v[1] += f.y; v[2] += f.z; v[3] += f.w;
           }
           float r4[4], b4v[4];
@@ -162,25 +173,52 @@ __device__ __forceinline__ void w3_epilogue_rows(const GemmP& p, const f32x16_t 
           quad_to_f32<Tag>(BLEND ? blv[k] : rqv[k], b4v);
 #pragma unroll
           for (int e = 0; e < 4; ++e) v[e] = alpha * b4v[e] + one_m_alpha * (v[e] + r4[e]);
-          stq<Tag>(r_out, (int)(o_out + pass * s_out), v);
+          const quad_t packed = f32_to_quad<Tag>(v);
+          st64(r_out, (int)(o_out + pass * s_out), packed.x, packed.y);
+          if constexpr (STATS) {                             // (rows >= m never occur: stats are granted for m % tile rows == 0 only)
+            float sv[4];
+            quad_to_f32<Tag>(packed, sv);
+            *(float4*)(ebuf + strip_off(r, qq, q_per_row)) = make_float4(sv[0], sv[1], sv[2], sv[3]);
+          }
         }
       }
     }
+    if constexpr (STATS) colstat_strip(ebuf, q_per_row, lane, sstage + jc * 32, sstage + 160 + jc * 32, i == 0);
   }
   }
 }
 // uniform dispatch over the operand variants (each straight-line); NI fragment rows starting at row mb0
 template <typename Tag, int NI, bool XCHG>
 __device__ __forceinline__ void w3_epilogue_dispatch(const GemmP& p, const f32x16_t (*accs)[5], const float* rss, char* ebuf, int mb0, int ncol0,
-                                                     int lane, const f32x16_t (&give)[5], char* xbuf, const char* pbuf) {
+                                                     int lane, const f32x16_t (&give)[5], char* xbuf, const char* pbuf, float* sstage) {
   const float alpha = p.blend ? p.alpha : 0.0f;
   const bool blend_is_res = p.blend && p.blend == p.residual && p.ld_blend == p.ld_res;
   const bool film = p.rowvec != nullptr, res = p.residual != nullptr, bl = p.blend && !blend_is_res;
-#define W3_RUN(F, R, B) w3_epilogue_rows<Tag, NI, F, R, B, XCHG>(p, accs, rss, ebuf, mb0, ncol0, lane, alpha, give, xbuf, pbuf)
-  if (bl) { if (film) W3_RUN(true, true, true); else W3_RUN(false, true, true); }
-  else if (res) { if (film) W3_RUN(true, true, false); else W3_RUN(false, true, false); }
-  else { if (film) W3_RUN(true, false, false); else W3_RUN(false, false, false); }
+#define W3_RUN(F, R, B, S) w3_epilogue_rows<Tag, NI, F, R, B, XCHG, S>(p, accs, rss, ebuf, mb0, ncol0, lane, alpha, give, xbuf, pbuf, sstage)
+  if (p.stats) {                                             // (never with a blend tensor distinct from the residual: tt_gemm_stats_rows)
+    if (res) { if (film) W3_RUN(true, true, false, true); else W3_RUN(false, true, false, true); }
+    else { if (film) W3_RUN(true, false, false, true); else W3_RUN(false, false, false, true); }
+  }
+  else if (bl) { if (film) W3_RUN(true, true, true, false); else W3_RUN(false, true, true, false); }
+  else if (res) { if (film) W3_RUN(true, true, false, false); else W3_RUN(false, true, false, false); }
+  else { if (film) W3_RUN(true, false, false, false); else W3_RUN(false, false, false, false); }
 #undef W3_RUN
+}
+
+// ---- GemmP.stats, tile level: the waves' staging rows ([wave][2][160] floats at `st0`) of the waves that share a column half,
+// added in a fixed order; thread c < 320 finishes column c.  `nw` waves per column half: wave index of (k, half) = wave_of(k, half).
+template <typename F> __device__ __forceinline__ void w3_stats_tile(const GemmP& p, const float* st0, int tid, int tile_m, int n0, int nw, F wave_of) {
+  __syncthreads();
+  if (tid < 320) {
+    const int half = tid >= 160 ? 1 : 0, col = tid - half * 160;
+    float a = 0.f, b = 0.f;
+    for (int k = 0; k < nw; ++k) {
+      const float* row = st0 + wave_of(k, half) * 320;
+      a += row[col]; b += row[160 + col];
+    }
+    p.stats[((long)tile_m * 2) * p.n + n0 + tid] = a;
+    p.stats[((long)tile_m * 2 + 1) * p.n + n0 + tid] = b;
+  }
 }
 
 // ---- split-K form of the above for ONE fragment row of gemm_w320h_kernel (p.splitk > 1): the fp32 partial sums of K slice `split`
@@ -459,7 +497,9 @@ __global__ __launch_bounds__(512, 2) void gemm_w320_kernel(const GemmP p) {
 
   // ---- epilogue in the (now free) ring: one 8 KiB strip per wave
   char* ebuf = smem + wid * 8192;
-  w3_epilogue_dispatch<Tag, FM, false>(p, acc, rs, ebuf, m0 + wr * 64, n0 + wc * 160, lane, acc[0], nullptr, nullptr);
+  float* sst = (float*)(smem + 9 * 8192);                    // statistics staging rows behind the strips and the LayerNorm partials: [wave][2][160]
+  w3_epilogue_dispatch<Tag, FM, false>(p, acc, rs, ebuf, m0 + wr * 64, n0 + wc * 160, lane, acc[0], nullptr, nullptr, sst + wid * 320);
+  if (p.stats) w3_stats_tile(p, sst, tid, tile_m, n0, 4, [](int k, int half) { return half * 4 + k; });      // wid = wc * 4 + wr
 }
 
 // ---- gemm_w320h: the half-height variant, 128 x 320 x 64 tiles, for problems with too few rows for a round of 256-row tiles
@@ -718,14 +758,17 @@ __global__ __launch_bounds__(512, 2) void gemm_w320h_kernel(const GemmP p) {
     else w3_partial_row(p, acc[1], ebuf, mb + 32, ncol0, lane, split, acc[0], xbuf, pbuf);
     return;
   }
-  if (grp == 0) w3_epilogue_dispatch<Tag, 1, true>(p, &acc[0], &rs[0], ebuf, mb, ncol0, lane, acc[1], xbuf, pbuf);
-  else w3_epilogue_dispatch<Tag, 1, true>(p, &acc[1], &rs[1], ebuf, mb + 32, ncol0, lane, acc[0], xbuf, pbuf);
+  float* sst = (float*)(smem + 16 * 8192);                   // statistics staging rows behind the strips and the exchange buffers
+  if (grp == 0) w3_epilogue_dispatch<Tag, 1, true>(p, &acc[0], &rs[0], ebuf, mb, ncol0, lane, acc[1], xbuf, pbuf, sst + wid * 320);
+  else w3_epilogue_dispatch<Tag, 1, true>(p, &acc[1], &rs[1], ebuf, mb + 32, ncol0, lane, acc[0], xbuf, pbuf, sst + wid * 320);
+  // wid = grp * 4 + wr * 2 + wc: the four waves (K half, row half) of a column half, rows in order
+  if (p.stats) w3_stats_tile(p, sst, tid, tile_m, n0, 4, [](int k, int half) { return (k & 1) * 4 + (k >> 1) * 2 + half; });
 }
 
 template <typename Tag, int MODE, int LNROWS>
 static void launch_w320_inst(GemmP& p, hipStream_t st) {
-  constexpr int lds = 2 * 73728;                             // two slots (the epilogue strips and the LayerNorm partials reuse them)
-  static_assert(lds <= 160 * 1024 && 8 * 8192 + 8192 <= lds, "w320 LDS");
+  constexpr int lds = 2 * 73728;                             // two slots (the epilogue strips, the LayerNorm partials and the statistics staging rows reuse them)
+  static_assert(lds <= 160 * 1024 && 9 * 8192 + 8 * 320 * 4 <= lds, "w320 LDS");
   static unsigned long long attr_done = 0;
   tt_lds_opt_in((const void*)gemm_w320_kernel<Tag, MODE, LNROWS>, lds, &attr_done);
   hipLaunchKernelGGL((gemm_w320_kernel<Tag, MODE, LNROWS>), dim3(p.tiles_m * p.tiles_n), dim3(512), lds, st, p);
@@ -746,8 +789,8 @@ void launch_w320_f16(GemmP& p, hipStream_t st) { launch_w320_tag<f16_tag>(p, st)
 
 template <typename Tag, int MODE, int LNROWS>
 static void launch_w320h_inst(GemmP& p, hipStream_t st) {
-  constexpr int lds = 128 * 1024;                            // two 56 KiB slots; the epilogue reuses them: 8 strips + 8 exchange buffers of 8 KiB
-  static_assert(lds <= 160 * 1024 && 2 * 57344 <= lds && 16 * 8192 <= lds, "w320h LDS");
+  constexpr int lds = 128 * 1024 + 8 * 320 * 4;              // two 56 KiB slots; the epilogue reuses them: 8 strips + 8 exchange buffers of 8 KiB, + the statistics staging rows
+  static_assert(lds <= 160 * 1024 && 2 * 57344 <= lds && 16 * 8192 + 8 * 320 * 4 <= lds, "w320h LDS");
   static unsigned long long attr_done = 0;
   tt_lds_opt_in((const void*)gemm_w320h_kernel<Tag, MODE, LNROWS>, lds, &attr_done);
   hipLaunchKernelGGL((gemm_w320h_kernel<Tag, MODE, LNROWS>), dim3(p.tiles_m * p.tiles_n * p.splitk), dim3(512), lds, st, p);

@@ -431,6 +431,99 @@ __global__ __launch_bounds__(512) void gn_group_kernel(const char* x0, int c0, c
     }
   }
 }
+// ---- GroupNorm from the PRODUCER's tile sums (tt_gemm stats_out; round 5): the conv / Linear launch that wrote x also left, per tile
+// of R rows and per channel, the sum and the sum of squares of what it stored.  A segment (one image, or the frames x hw rows of one
+// video for the temporal ResBlock's cross-frame statistics) is a whole number of tiles, so its statistics are a sum over seg_rows / R
+// tile rows -- a few KB instead of a pass over the tensor.  Block (row part of a segment, slice of gpb groups): adds the tile sums of its
+// channels (fp64, fixed order: bit-reproducible), folds channels into groups, then streams ITS rows once: normalise, activate, store.
+// x crosses HBM once in each direction and there is one launch per GroupNorm, for per-image and cross-frame statistics alike
+// (before: two passes in one launch, or three launches).  Slices of one row part go to ONE XCD, as in gn_group_kernel.
+template <typename Tag>
+__global__ __launch_bounds__(512) void gn_tiles_kernel(const char* x, int C, const float* stats, int R, int seg_rows, int nunits, int parts,
+                                                       int gpb, int nslices, int rlanes, const float* gamma, const float* beta, float eps,
+                                                       int silu, char* y, long ldy) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  __shared__ float s_mean[GN_GROUPS], s_rstd[GN_GROUPS];
+  kernarg_touch<96>();
+  const int cpg = C / GN_GROUPS;
+  const int L = blockIdx.x, xcd = L & 7, t = L >> 3;
+  const int slice = t % nslices, unit = xcd + 8 * (t / nslices);
+  if (unit >= nunits) return;
+  const int seg = unit / parts, part = unit - seg * parts;
+  const int nch = gpb * cpg, nv = nch >> 3, ch_lo = slice * nch;
+  const int tid = threadIdx.x;
+  constexpr int ES = Elem<Tag>::ES;
+  // ---- statistics: tile rows of this segment, channels of this slice.  Thread (channel c, lane kl of KL) adds tiles kl, kl + KL, ..
+  double* pd = (double*)smem;                                // [KL][nch][2], then the channel totals in row 0
+  const int T = seg_rows / R, KL = 512 / nch;
+  {
+    const int c = tid % nch, kl = tid / nch;
+    if (kl < KL) {
+      double a = 0.0, b = 0.0;
+      const float* base = stats + ((long)seg * T * 2) * C + ch_lo + c;
+      for (int k = kl; k < T; k += KL) { a += (double)base[(long)k * 2 * C]; b += (double)base[(long)k * 2 * C + C]; }
+      pd[(kl * nch + c) * 2] = a; pd[(kl * nch + c) * 2 + 1] = b;
+    }
+  }
+  __syncthreads();
+  if (tid < nch) {
+    double a = 0.0, b = 0.0;
+    for (int kl = 0; kl < KL; ++kl) { a += pd[(kl * nch + tid) * 2]; b += pd[(kl * nch + tid) * 2 + 1]; }
+    pd[tid * 2] = a; pd[tid * 2 + 1] = b;                    // (row 0 of the table: only thread `tid` read these two entries)
+  }
+  __syncthreads();
+  if (tid < gpb) {
+    double a = 0.0, b = 0.0;
+    for (int c = 0; c < cpg; ++c) { a += pd[(tid * cpg + c) * 2]; b += pd[(tid * cpg + c) * 2 + 1]; }
+    const double cnt = (double)seg_rows * cpg, mean = a / cnt;
+    double var = b / cnt - mean * mean;
+    if (var < 0.0) var = 0.0;
+    s_mean[tid] = (float)mean;
+    s_rstd[tid] = (float)(1.0 / sqrt(var + (double)eps));
+  }
+  __syncthreads();
+  // ---- apply: rows [r_lo, r_hi) of the segment, this slice's channels
+  const int myv = tid % nv, myr = tid / nv;
+  if (myr >= rlanes) return;
+  const int ch = ch_lo + myv * 8;
+  float sc[8], sh[8];
+#pragma unroll
+  for (int e = 0; e < 8; ++e) {
+    const int gg = (myv * 8 + e) / cpg;
+    sc[e] = s_rstd[gg] * gamma[ch + e];
+    sh[e] = beta[ch + e] - s_mean[gg] * sc[e];
+  }
+  const int per = (seg_rows + parts - 1) / parts, r_lo = part * per, r_hi = min(seg_rows, r_lo + per);
+  const char* pbase = x + (((long)seg * seg_rows) * C + ch) * ES;
+  char* ybase = y + (((long)seg * seg_rows) * ldy + ch) * ES;
+  const long rstride = (long)C * ES, ystride = ldy * ES;
+  int r = r_lo + myr;
+  for (; r + 3 * rlanes < r_hi; r += 4 * rlanes) {
+    float f[4][8];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) load8<Tag>(pbase + (long)(r + k * rlanes) * rstride, f[k]);
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+#pragma unroll
+      for (int e = 0; e < 8; ++e) {
+        const float v = fmaf(f[k][e], sc[e], sh[e]);
+        f[k][e] = silu ? silu_f(v) : v;
+      }
+      store8<Tag>(ybase + (long)(r + k * rlanes) * ystride, f[k]);
+    }
+  }
+  for (; r < r_hi; r += rlanes) {
+    float f[8];
+    load8<Tag>(pbase + (long)r * rstride, f);
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      const float v = fmaf(f[e], sc[e], sh[e]);
+      f[e] = silu ? silu_f(v) : v;
+    }
+    store8<Tag>(ybase + (long)r * ystride, f);
+  }
+}
+
 // groups per block: the smallest count whose channels fill whole 8-channel vectors, doubled towards 128-byte row slices while an
 // image keeps at least 8 slices (16 x 28 x 1280: 80-byte slices 47 us, 160-byte slices 26 us).  0: the channel counts do not allow it (a source boundary inside a vector cannot happen: c0 is a multiple of 8).
 // Independent of the image count, so tt_groupnorm_small_supported can answer for the launch.
@@ -562,6 +655,39 @@ extern "C" int tt_groupnorm_small(const void* x0, int32_t c0, const void* x1, in
   if (dtype == TT_BF16) TT_GNS(bf16_tag, 0); else if (dtype == TT_F16) TT_GNS(f16_tag, 1); else TT_GNS(f32_tag, 2);
 #undef TT_GNS
   TT_CHECK_LAUNCH("tt_groupnorm_small");
+  return TT_OK;
+}
+
+extern "C" int tt_groupnorm_tiles_supported(int32_t seg_rows, int32_t c, int32_t stat_rows, int32_t dtype) {
+  const int es = dtype == TT_F32 ? 4 : 2;
+  if (seg_rows <= 0 || c <= 0 || stat_rows <= 0 || (c % GN_GROUPS) || (c & 7) || seg_rows % stat_rows) return 0;
+  return gn_group_gpb(c, es) > 0 ? 1 : 0;
+}
+extern "C" int tt_groupnorm_tiles(const void* x, int32_t c, const float* stats, int32_t stat_rows, int32_t nseg, int32_t seg_rows,
+                                  const float* gamma, const float* beta, float eps, int32_t silu, void* y, int64_t ldy, int32_t dtype,
+                                  tt_stream_t stream) {
+  if (!x || !stats || !gamma || !beta || !y) TT_FAIL(TT_EINVAL, "tt_groupnorm_tiles: null operand");
+  if (nseg <= 0 || (ldy & 7) || ldy < c) TT_FAIL(TT_EINVAL, "tt_groupnorm_tiles: segments / output stride");
+  if (dtype != TT_BF16 && dtype != TT_F16 && dtype != TT_F32) TT_FAIL(TT_EINVAL, "tt_groupnorm_tiles: bad dtype");
+  if (!tt_groupnorm_tiles_supported(seg_rows, c, stat_rows, dtype))
+    TT_FAIL(TT_EUNSUPPORTED, "tt_groupnorm_tiles: %d rows per segment must be a multiple of the %d statistics rows, C = %d a multiple of 32", seg_rows, stat_rows, c);
+  const int es = dtype == TT_F32 ? 4 : 2;
+  const int gpb = gn_group_gpb(c, es), nslices = GN_GROUPS / gpb, nch = gpb * (c / GN_GROUPS), nv = nch >> 3;
+  // row parts per segment: ~2 blocks per CU over the launch, at least 128 rows each
+  int parts = (512 + nseg * nslices - 1) / (nseg * nslices);
+  if (parts > seg_rows / 128) parts = seg_rows / 128;
+  if (parts < 1) parts = 1;
+  const int per = (seg_rows + parts - 1) / parts;
+  int rlanes = 512 / nv;
+  if (rlanes > per) rlanes = per;
+  const int nunits = nseg * parts, blocks = ((nunits + 7) / 8) * 8 * nslices;
+  const size_t lds = (size_t)(512 / nch) * nch * 2 * sizeof(double);
+  hipStream_t st = (hipStream_t)stream;
+#define TT_GNT(TAG) hipLaunchKernelGGL(gn_tiles_kernel<TAG>, dim3(blocks), dim3(512), lds, st, (const char*)x, (int)c, stats, (int)stat_rows, (int)seg_rows, \
+                                       nunits, parts, gpb, nslices, rlanes, gamma, beta, eps, (int)silu, (char*)y, (long)ldy)
+  if (dtype == TT_BF16) TT_GNT(bf16_tag); else if (dtype == TT_F16) TT_GNT(f16_tag); else TT_GNT(f32_tag);
+#undef TT_GNT
+  TT_CHECK_LAUNCH("tt_groupnorm_tiles");
   return TT_OK;
 }
 

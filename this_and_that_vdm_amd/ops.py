@@ -87,8 +87,12 @@ def gemm(a0: torch.Tensor, w: torch.Tensor, *, a1: Optional[torch.Tensor] = None
          bias=None, acc_scale: float = 1.0, rowvec=None, rowvec_rows: int = 0, rowvec_mod: int = 0, geglu: bool = False, residual=None,
          blend=None, alpha: float = 0.0, out: Optional[torch.Tensor] = None, out_f32: bool = False, m: Optional[int] = None,
          out_col_pad: Optional[Tuple[int, int]] = None, ln_fold: int = 0, ln_eps: float = 1e-5,
-         out_fp8: bool = False) -> torch.Tensor:
+         out_fp8: bool = False, stats: int = 0) -> torch.Tensor:
     """out[m, n] = epilogue(gather(a0|a1) @ w.T); see TtGemmArgs in include/ttvdm.h.
+    stats = S > 0: the output will be read by a GroupNorm whose segments are S rows (h*w for per-image statistics, frames*h*w for the
+    temporal ResBlock) -- ask the launch for its per-tile column sums (TtGemmArgs.stats_out).  When the route has a statistics
+    epilogue AND S is a whole number of its tiles they are attached to the returned tensor (``out._tt_stats = (buffer, rows per
+    tile)``) and groupnorm() normalises in one pass from them; otherwise the launch runs without them (no cost).
     conv = (nimg, hin, win, hout, wout, stride, upsample); tconv = (frames, hw).
     ln_fold: 1 = rows of a0 / 2 = rows of w are LayerNorm inputs (weights pre-folded by packing.fold_layernorm).
     out_fp8: the output is stored as OCP e4m3 (torch.float8_e4m3fn), the operand format of attention(..., fp8 path)."""
@@ -137,8 +141,18 @@ def gemm(a0: torch.Tensor, w: torch.Tensor, *, a1: Optional[torch.Tensor] = None
     if need:
         ws = _workspace(need, a0.device)
         g.ws, g.ws_bytes = ws.data_ptr(), ws.numel()
+    if hasattr(out, "_tt_stats"):
+        del out._tt_stats                                   # `out` is being overwritten: sums attached by an earlier launch are stale
+    sbuf = None
+    if stats and GN_TILES:
+        srows = lib.tt_gemm_stats_rows(C.byref(g))
+        if srows > 0 and lib.tt_groupnorm_tiles_supported(int(stats), n, srows, g.dtype):
+            sbuf = torch.empty(((g.m + srows - 1) // srows, 2, n), dtype=torch.float32, device=a0.device)
+            g.stats_out = sbuf.data_ptr()
     ev = _prof_begin()
     check(lib.tt_gemm(C.byref(g), _stream()), "tt_gemm")
+    if sbuf is not None:
+        out._tt_stats = (sbuf, srows)
     if ev is not None:
         cfg = (C.c_int32 * 7)()
         lib.tt_gemm_plan(C.byref(g), cfg)
@@ -285,12 +299,33 @@ GN_SMALL = os.environ.get("TT_GN_SMALL", "1") != "0"      # A/B switch for the o
 GN_CROSS_MAX_ROWS = int(os.environ.get("TT_GN_CROSS_ROWS", "0"))
 
 
+# GroupNorm from the producer's tile sums (tt_gemm stats_out -> tt_groupnorm_tiles): on by default, TT_GN_TILES=0 keeps every
+# GroupNorm on the statistics-pass kernels (A/B)
+GN_TILES = os.environ.get("TT_GN_TILES", "1") != "0"
+_GN_EMULATE = os.environ.get("TT_GN_EMULATE", "0") == "1"
+_GN_EMU_CACHE = {}
+
+
 def groupnorm(x0, x1, nimg, hw, frames_per_group, gamma, beta, eps, silu: bool):
     """act(group_norm(x0 | x1)) -> new tensor.  Small per-image problems take ONE launch (tt_groupnorm_small), everything else
     tt_groupnorm_stats + tt_groupnorm_apply."""
     lib = _lib.load()
     c0 = x0.shape[-1]
     c1 = 0 if x1 is None else x1.shape[-1]
+    if _GN_EMULATE:          # timing experiment only (wrong numbers): what a statistics-free consumer would cost -- one apply launch
+        key = (nimg, c0 + c1, x0.device)
+        ss = _GN_EMU_CACHE.get(key)
+        if ss is None:
+            ss = _GN_EMU_CACHE[key] = (torch.ones((nimg, c0 + c1), dtype=torch.float32, device=x0.device), torch.zeros((nimg, c0 + c1), dtype=torch.float32, device=x0.device))
+        return groupnorm_apply(x0, x1, nimg, hw, ss[0], ss[1], silu)
+    st = getattr(x0, "_tt_stats", None) if (GN_TILES and x1 is None) else None
+    if st is not None and nimg % frames_per_group == 0 and x0.is_contiguous() and st[0].shape[2] == c0 and \
+            lib.tt_groupnorm_tiles_supported(frames_per_group * hw, c0, st[1], _code(x0.dtype)):
+        # the producer of x0 left per-tile column sums: one pass over x0, one launch, per-image and cross-frame statistics alike
+        out = torch.empty((nimg * hw, c0), dtype=x0.dtype, device=x0.device)
+        check(lib.tt_groupnorm_tiles(_p(x0), c0, _p(st[0]), st[1], nimg // frames_per_group, frames_per_group * hw, _p(gamma), _p(beta), eps,
+                                     int(silu), _p(out), out.stride(0), _code(x0.dtype), _stream()), "tt_groupnorm_tiles")
+        return out
     if GN_SMALL and frames_per_group > 1 and nimg % frames_per_group == 0 and frames_per_group * hw <= GN_CROSS_MAX_ROWS and \
             lib.tt_groupnorm_small_supported(frames_per_group * hw, c0 + c1, _code(x0.dtype)):
         nimg, hw, frames_per_group = nimg // frames_per_group, frames_per_group * hw, 1
@@ -323,6 +358,8 @@ def add_rowvec(x, rowvec, rows_per_vec: int, nvec: int, out=None):
     rows, c = x.shape
     assert x.stride(1) == 1 and rowvec.dtype == torch.float32 and rowvec.stride(1) == 1
     y = torch.empty((rows, c), dtype=x.dtype, device=x.device) if out is None else out
+    if hasattr(y, "_tt_stats"):
+        del y._tt_stats
     assert y.shape == x.shape and y.stride(1) == 1 and y.dtype == x.dtype
     check(lib.tt_add_rowvec(_p(x), x.stride(0), rows, c, _p(rowvec), rowvec.stride(0), rows_per_vec, nvec, _p(y), y.stride(0),
                             _code(x.dtype), _stream()), "tt_add_rowvec")

@@ -92,4 +92,4 @@ class TransformerSpatioTemporalModel(_Packable):
             else:
                 hs = blk(hs, g, ctx)
                 hs = tblk(hs, pos, g, ctx, self.alpha)
-        return ops.gemm(hs, self.w_out, bias=self.b_out, residual=x)
+        return ops.gemm(hs, self.w_out, bias=self.b_out, residual=x, stats=g.hw)        # the next ResBlock's norm1 (per image) reads it

@@ -294,7 +294,8 @@ class ResnetBlock2D(_Packable):
                                rowvec_rows=g.frames * g.hw if film is not None else 0)
         else:
             a = ops.groupnorm(x0, x1, g.n, g.hw, 1, self.g1, self.be1, self.eps, True)
-            hmid = ops.gemm(a, self.w1, mode=1, conv=conv, bias=self.b1, rowvec=film, rowvec_rows=g.frames * g.hw if film is not None else 0)
+            hmid = ops.gemm(a, self.w1, mode=1, conv=conv, bias=self.b1, rowvec=film, rowvec_rows=g.frames * g.hw if film is not None else 0,
+                            stats=g.hw)                      # norm2 (per image) reads it: per-tile column sums from the epilogue (ops.groupnorm)
         if self.conv_shortcut is not None:
             xs = ops.gemm(x0, self.ws, a1=x1, bias=self.bs)
         else:
@@ -305,7 +306,8 @@ class ResnetBlock2D(_Packable):
             st2 = ops.groupnorm_stats(hmid, None, g.n, g.hw, 1, self.g2, self.be2, self.eps)
             return ops.conv3x3(hmid, None, self.w2, g.n, g.h, g.w, gn=st2, silu=True, bias=self.b2, residual=xs)
         a = ops.groupnorm(hmid, None, g.n, g.hw, 1, self.g2, self.be2, self.eps, True)
-        return ops.gemm(a, self.w2, mode=1, conv=conv, bias=self.b2, residual=xs)
+        # (read by the temporal block's norm1: statistics over the frames x h x w rows of a video)
+        return ops.gemm(a, self.w2, mode=1, conv=conv, bias=self.b2, residual=xs, stats=g.frames * g.hw)
 
 
 class TemporalResnetBlock(_Packable):
@@ -335,10 +337,11 @@ class TemporalResnetBlock(_Packable):
         film = g.film(ctx.film, *self.film) if self.film is not None else None
         a = _gn(s, None, g, g.frames, self.g1, self.be1, self.eps, True)
         t = ops.gemm(a, self.w1, mode=2, tconv=(g.frames, g.hw), bias=self.b1, rowvec=film,
-                     rowvec_rows=g.frames * g.hw if film is not None else 0)
+                     rowvec_rows=g.frames * g.hw if film is not None else 0, stats=g.frames * g.hw)
         a = _gn(t, None, g, g.frames, self.g2, self.be2, self.eps, True)
         # x_temporal = s + conv2(...);  out = alpha*s + (1-alpha)*x_temporal
-        return ops.gemm(a, self.w2, mode=2, tconv=(g.frames, g.hw), bias=self.b2, residual=s, blend=s, alpha=alpha)
+        # (the block's output: the transformer's GroupNorm or the next ResBlock's norm1 reads it)
+        return ops.gemm(a, self.w2, mode=2, tconv=(g.frames, g.hw), bias=self.b2, residual=s, blend=s, alpha=alpha, stats=g.hw)
 
 
 class AlphaBlender(nn.Module):
@@ -392,7 +395,7 @@ class Downsample2D(_Packable):
 
     def forward(self, x, g: Geom):
         ho, wo = (g.h + 2 - 3) // 2 + 1, (g.w + 2 - 3) // 2 + 1
-        out = ops.gemm(x, self.w, mode=1, conv=(g.n, g.h, g.w, ho, wo, 2, 0), bias=self.b)
+        out = ops.gemm(x, self.w, mode=1, conv=(g.n, g.h, g.w, ho, wo, 2, 0), bias=self.b, stats=ho * wo)
         return out, Geom(g.batch, g.frames, ho, wo, g.batch0, g.batch_total)
 
 
@@ -409,7 +412,7 @@ class Upsample2D(_Packable):
 
     def forward(self, x, g: Geom):
         # nearest x2 is an index map inside the conv gather: never materialised
-        out = ops.gemm(x, self.w, mode=1, conv=(g.n, g.h, g.w, 2 * g.h, 2 * g.w, 1, 1), bias=self.b)
+        out = ops.gemm(x, self.w, mode=1, conv=(g.n, g.h, g.w, 2 * g.h, 2 * g.w, 1, 1), bias=self.b, stats=4 * g.hw)
         return out, Geom(g.batch, g.frames, 2 * g.h, 2 * g.w, g.batch0, g.batch_total)
 
 

@@ -124,7 +124,7 @@ class ControlNetModel(DenoiserBase, ConfigMixin):
     # ---- forward
     def encode_tokens(self, x_tok, g: Geom, ctx):
         """conv_in_concat + 4 down blocks + mid block -> (12 skips [(tok, geom)], mid tokens, mid geom)."""
-        x = ops.gemm(x_tok, self._w_in, mode=1, conv=(g.n, g.h, g.w, g.h, g.w, 1, 0), bias=self._b_in)
+        x = ops.gemm(x_tok, self._w_in, mode=1, conv=(g.n, g.h, g.w, g.h, g.w, 1, 0), bias=self._b_in, stats=g.hw)
         x, gm, skips = self._encode(x, g, ctx)
         return skips, self.mid_block(x, gm, ctx), gm
 

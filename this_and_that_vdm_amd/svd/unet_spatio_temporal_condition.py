@@ -113,7 +113,7 @@ class UNetSpatioTemporalConditionModel(DenoiserBase, ConfigMixin):
     # ---- forward
     def encode_tokens(self, x_tok, g: Geom, ctx):
         """conv_in + 4 down blocks + mid block -> (x_mid, geom_mid, skips[12]) ; no ControlNet terms yet."""
-        x = ops.gemm(x_tok, self._w_in, mode=1, conv=(g.n, g.h, g.w, g.h, g.w, 1, 0), bias=self._b_in)
+        x = ops.gemm(x_tok, self._w_in, mode=1, conv=(g.n, g.h, g.w, g.h, g.w, 1, 0), bias=self._b_in, stats=g.hw)
         x, gm, skips = self._encode(x, g, ctx)
         return self.mid_block(x, gm, ctx), gm, skips
 
