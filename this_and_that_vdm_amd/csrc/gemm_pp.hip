@@ -333,8 +333,13 @@ __global__ __launch_bounds__(512, 2) void gemm_pp_kernel(const GemmP p) {
               const f32pk_t r2 = {rs[i], rs[i]};
               const f32pk_t g01 = (f32pk_t){acc[i][j][(2 * tt + 1) * 4], acc[i][j][(2 * tt + 1) * 4 + 1]} * r2 + (f32pk_t){bg.x, bg.y};
               const f32pk_t g23 = (f32pk_t){acc[i][j][(2 * tt + 1) * 4 + 2], acc[i][j][(2 * tt + 1) * 4 + 3]} * r2 + (f32pk_t){bg.z, bg.w};
-              const f32pk_t v01 = ((f32pk_t){acc[i][j][(2 * tt) * 4], acc[i][j][(2 * tt) * 4 + 1]} * r2 + (f32pk_t){bv.x, bv.y}) * gelu_erf_pk(g01);
-              const f32pk_t v23 = ((f32pk_t){acc[i][j][(2 * tt) * 4 + 2], acc[i][j][(2 * tt) * 4 + 3]} * r2 + (f32pk_t){bv.z, bv.w}) * gelu_erf_pk(g23);
+#ifdef TT_GELU_ERF_AS          // A/B build only (make variant): the Abramowitz-Stegun erf form of rounds 3-4
+#define TT_PP_GELU gelu_erf_pk
+#else
+#define TT_PP_GELU gelu_sig_pk
+#endif
+              const f32pk_t v01 = ((f32pk_t){acc[i][j][(2 * tt) * 4], acc[i][j][(2 * tt) * 4 + 1]} * r2 + (f32pk_t){bv.x, bv.y}) * TT_PP_GELU(g01);
+              const f32pk_t v23 = ((f32pk_t){acc[i][j][(2 * tt) * 4 + 2], acc[i][j][(2 * tt) * 4 + 3]} * r2 + (f32pk_t){bv.z, bv.w}) * TT_PP_GELU(g23);
               v[0] = v01.x; v[1] = v01.y; v[2] = v23.x; v[3] = v23.y;
             }
 #endif

@@ -144,7 +144,9 @@ def gemm(a0: torch.Tensor, w: torch.Tensor, *, a1: Optional[torch.Tensor] = None
     if hasattr(out, "_tt_stats"):
         del out._tt_stats                                   # `out` is being overwritten: sums attached by an earlier launch are stale
     sbuf = None
-    if stats and GN_TILES:
+    # (only for outputs up to the finest level's size at 256x448: the statistics epilogue costs 1-2.6 us PER TILE of a workgroup, so a
+    # launch that walks 3-4 tiles per CU -- 512x896 latents -- pays more than the consumer's saved pass: 107.5 -> 108.5 ms/step, one call)
+    if stats and GN_TILES and g.m * n <= GN_TILES_MAX_ELEMS:
         srows = lib.tt_gemm_stats_rows(C.byref(g))
         if srows > 0 and lib.tt_groupnorm_tiles_supported(int(stats), n, srows, g.dtype):
             sbuf = torch.empty(((g.m + srows - 1) // srows, 2, n), dtype=torch.float32, device=a0.device)
@@ -302,6 +304,7 @@ GN_CROSS_MAX_ROWS = int(os.environ.get("TT_GN_CROSS_ROWS", "0"))
 # GroupNorm from the producer's tile sums (tt_gemm stats_out -> tt_groupnorm_tiles): on by default, TT_GN_TILES=0 keeps every
 # GroupNorm on the statistics-pass kernels (A/B)
 GN_TILES = os.environ.get("TT_GN_TILES", "1") != "0"
+GN_TILES_MAX_ELEMS = int(os.environ.get("TT_GN_TILES_MAX_ELEMS", str(17 << 20)))
 _GN_EMULATE = os.environ.get("TT_GN_EMULATE", "0") == "1"
 _GN_EMU_CACHE = {}
 
