@@ -918,7 +918,8 @@ def test_gemm_periodic_row_vector(ops, dtype, m, n, k, rows_per, mod):
 
 
 @pytest.mark.parametrize("dtype", DTYPES)
-@pytest.mark.parametrize("case", ["w320_conv", "w320_linear_res", "w320_tconv_blend", "w320h_conv", "tiled_linear", "tiled_tconv", "tiled_small"])
+@pytest.mark.parametrize("case", ["w320_conv", "w320_linear_res", "w320_tconv_blend", "w320h_conv", "tiled_linear", "tiled_tconv", "tiled_small",
+                                  "splitk_conv_l3", "splitk_tconv_l3", "splitk_conv_l2"])
 def test_gemm_output_statistics_and_groupnorm_from_tiles(ops, dtype, case):
     """TtGemmArgs.stats_out: per (row tile, column) sum / sum of squares of the STORED output, on every route that has the epilogue
     (256 x 320 and 128 x 320 big tiles, the tiled template), against sums over the stored tensor; then tt_groupnorm_tiles (one pass
@@ -929,9 +930,14 @@ def test_gemm_output_statistics_and_groupnorm_from_tiles(ops, dtype, case):
     g = dict(w320_conv=dict(nimg=28, h=32, w=56, cin=64, n=320, mode=1), w320_linear_res=dict(rows=50176, k=128, n=320, mode=0, res=True),
              w320_tconv_blend=dict(nimg=28, h=32, w=56, cin=64, n=320, mode=2, blend=True), w320h_conv=dict(nimg=28, h=16, w=28, cin=64, n=640, mode=1),
              tiled_linear=dict(rows=3584, k=256, n=640, mode=0, res=True), tiled_tconv=dict(nimg=8, h=16, w=28, cin=128, n=640, mode=2),
-             tiled_small=dict(rows=1024, k=64, n=96, mode=0))[case]
-    if dtype == torch.float32 and case.startswith("w320"):
-        pytest.skip("the big-tile kernels serve 16-bit storage")
+             tiled_small=dict(rows=1024, k=64, n=96, mode=0),
+             # the split-K routes of the two coarsest levels: the reduction kernel takes the sums on tiles of the caller's height (28-row images)
+             splitk_conv_l3=dict(nimg=28, h=4, w=7, cin=1280, n=1280, mode=1, res=True, per_image=True), splitk_tconv_l3=dict(nimg=28, h=4, w=7, cin=1280, n=1280, mode=2, blend=True),
+             splitk_conv_l2=dict(nimg=28, h=8, w=14, cin=1280, n=1280, mode=1))[case]
+    if case.startswith("splitk"):
+        frames = 14
+    if dtype == torch.float32 and (case.startswith("w320") or case.startswith("splitk")):
+        pytest.skip("the big-tile kernels and the split-K plans serve 16-bit storage")
     mode, n = g["mode"], g["n"]
     if mode == 0:
         rows, k = g["rows"], g["k"]
@@ -953,7 +959,7 @@ def test_gemm_output_statistics_and_groupnorm_from_tiles(ops, dtype, case):
         kw["residual"] = res
     if g.get("blend"):
         kw.update(blend=res, alpha=0.3)
-    seg = frames * hw                                      # (the cross-frame segment: a multiple of hw)
+    seg = hw if g.get("per_image") else frames * hw        # the consumer's segment: one image, or the frames of a video
     plain = ops.gemm(a, w, **kw)
     out = ops.gemm(a, w, stats=seg, **kw)
     assert torch.equal(out, plain), "the statistics epilogue must not change the output"
@@ -964,6 +970,8 @@ def test_gemm_output_statistics_and_groupnorm_from_tiles(ops, dtype, case):
         assert r == 128
     elif case.startswith("w320"):
         assert r == 256
+    elif case.startswith("splitk"):
+        assert r == {"splitk_conv_l3": 28, "splitk_tconv_l3": 98, "splitk_conv_l2": 112}[case]     # largest divisor <= 128 of the requested segment
     x = out.float()
     want = torch.stack([x.view(rows // r, r, n).sum(1), (x * x).view(rows // r, r, n).sum(1)], 1)
     torch.testing.assert_close(sbuf, want, rtol=2e-5, atol=2e-4)

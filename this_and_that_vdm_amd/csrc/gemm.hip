@@ -317,10 +317,12 @@ extern "C" int32_t tt_gemm_stats_rows(const TtGemmArgs* a) {
   if (pp_ok(a) || pp_split_rows(a) || sq320_ok(a)) return 0;
   // the statistics variants exist for the straight-line epilogues: bias / scale / row vector of >= 32-row groups (or the even / odd
   // form) / residual / a blend with the residual itself -- not for the in-pass operand loads (gemm_kernel.h, `inpass`)
+  int32_t cfg[7];
+  if (tt_gemm_plan(a, cfg) != TT_OK) return 0;
+  if (cfg[6] != 1)                                                     // split-K: the reduction kernel takes the sums, on tiles of the caller's height
+    return (a->stats_rows > 0 && a->stats_rows <= 4096 && a->m % a->stats_rows == 0) ? a->stats_rows : 0;
   if (a->blend && !(a->blend == a->residual && a->ld_blend == a->ld_res)) return 0;
   if (a->rowvec && a->rowvec_rows < 32 && !(a->rowvec_rows == 1 && a->rowvec_mod == 2)) return 0;
-  int32_t cfg[7];
-  if (tt_gemm_plan(a, cfg) != TT_OK || cfg[6] != 1) return 0;          // split-K: the reduction kernel has no statistics
   if (cfg[0] > 128 && cfg[1] != 320 && a->residual) return 0;         // 256-row tiles of the tiled template read the residual in-pass
   return a->m % cfg[0] == 0 ? cfg[0] : 0;
 }
@@ -374,7 +376,7 @@ extern "C" int tt_gemm(const TtGemmArgs* a, tt_stream_t stream) {
   const int es = a->dtype == TT_F32 ? 4 : 2;         // bytes per stored element
   p.out = (char*)a->out; p.ldo = a->ldo; p.out_f32 = a->dtype == TT_F32 ? 0 : a->out_f32;   // TT_F32 stores fp32 anyway
   p.out_col_hw = a->out_col_hw; p.out_col_hwp = a->out_col_hwp;
-  p.ln_fold = a->ln_fold; p.ln_eps = a->ln_eps; p.out_fp8 = a->out_fp8; p.stats = a->stats_out;
+  p.ln_fold = a->ln_fold; p.ln_eps = a->ln_eps; p.out_fp8 = a->out_fp8; p.stats = a->stats_out; p.stat_rows = a->stats_rows;
   if (p.mode == 1) {
     if (p.nimg <= 0 || p.hin <= 0 || p.win <= 0 || p.hout <= 0 || p.wout <= 0 || p.stride < 1)
       TT_FAIL(TT_EINVAL, "tt_gemm: conv geometry");

@@ -51,6 +51,7 @@ struct GemmP {
   int ln_fold; float ln_eps;        // fused LayerNorm of the A rows (1) / W rows (2): see gemm_kernel, MODE 3 / 4
   int out_fp8;                      // store e4m3 bytes (operands of the fp8 attention path) instead of 16-bit values
   float* stats;                     // != NULL: per (row tile, column) sum and sum of squares of the stored output (TtGemmArgs.stats_out)
+  int stat_rows;                    // split-K launches: rows per statistics tile of the reduction kernel (TtGemmArgs.stats_rows)
   // launch-uniform divisors of the tiled template as multiply-shift pairs (fill_fastdivs, called by launch_cfg)
   FastDiv fd_splitk, fd_per_group, fd_group_m, fd_last_rows, fd_per_tap, fd_hwo, fd_wout, fd_hw, fd_frames, fd_rv_rows, fd_rv_mod;
 };
@@ -817,12 +818,13 @@ void gemm_kernel(const GemmP p) {
                           (!EARLY_RES && p.residual);
       constexpr std::false_type no{};
       constexpr std::true_type yes{};
+      const bool kstats = p.stats && p.splitk == 1;          // (a K slice leaves the sums to the reduction kernel)
       if (inpass) run(no, yes, no, no);                      // (never with statistics: tt_gemm_stats_rows)
-      else if (p.rowvec) { if (p.stats) run(yes, no, no, yes); else run(yes, no, no, no); }
+      else if (p.rowvec) { if (kstats) run(yes, no, no, yes); else run(yes, no, no, no); }
       else if (MODE == 0 && ES == 2 && p.out_fp8) {          // Q | K and V^T of the fp8 attention path (linear, no residual)
         if constexpr (MODE == 0 && ES == 2) run(no, no, yes, no);
-      } else { if (p.stats) run(no, no, no, yes); else run(no, no, no, no); }
-      if (p.stats) {                                       // the waves of one tile column, wave rows in order
+      } else { if (kstats) run(no, no, no, yes); else run(no, no, no, no); }
+      if (kstats) {                                        // the waves of one tile column, wave rows in order
         __syncthreads();
         const float* st0 = (const float*)(smem + STAT_OFF);
         for (int c = tid; c < BN; c += NT) {
@@ -1101,6 +1103,56 @@ __global__ __launch_bounds__(256) void splitk_epilogue_kernel(const GemmP p) {
   }
 }
 
+// ... the same with the GroupNorm tile sums of the output (GemmP.stats; the split-K routes of the two coarsest UNet levels): block (row tile of
+// p.stat_rows rows, chunk of 64 columns), thread (column quad, one of sixteen row lanes) walks its rows (two of a 28-row image), adds what it
+// stores; the row lanes meet in LDS in a fixed order.  The caller picks the tile height (any divisor of its GroupNorm segment).
+template <typename Tag>
+__global__ __launch_bounds__(256) void splitk_epilogue_stats_kernel(const GemmP p) {
+  __shared__ float red[16][16][8];
+  kernarg_touch<sizeof(GemmP)>();
+  const int R = p.stat_rows, rt = blockIdx.x, tid = threadIdx.x;
+  const int qd = tid & 15, rl = tid >> 4;
+  const int gn = (int)blockIdx.y * 64 + qd * 4;
+  float cs[4] = {0.f, 0.f, 0.f, 0.f}, cq[4] = {0.f, 0.f, 0.f, 0.f};
+  if (gn < p.n) {
+    for (int r = rl; r < R; r += 16) {
+      const int gm = rt * R + r;                              // < m: m is a multiple of R (tt_gemm_stats_rows)
+      float4 a = *(const float4*)(p.ws + (long)gm * p.n + gn);
+      for (int s2 = 1; s2 < p.splitk; ++s2) {
+        const float4 b = *(const float4*)(p.ws + ((long)s2 * p.m + gm) * p.n + gn);
+        a.x += b.x; a.y += b.y; a.z += b.z; a.w += b.w;
+      }
+      float v[4] = {a.x, a.y, a.z, a.w};
+      epilogue_quad<Tag>(p, gm, gn, v);
+#pragma unroll
+      for (int e = 0; e < 4; ++e) { const float x = round_store<Tag>(v[e]); cs[e] += x; cq[e] = fmaf(x, x, cq[e]); }
+    }
+  }
+#pragma unroll
+  for (int e = 0; e < 4; ++e) { red[rl][qd][e] = cs[e]; red[rl][qd][4 + e] = cq[e]; }
+  __syncthreads();
+  if (tid < 128) {                                            // thread (column quad, one of its eight sums): the sixteen row lanes in order
+    const int q2 = tid >> 3, e = tid & 7, c = (int)blockIdx.y * 64 + q2 * 4 + (e & 3);
+    if (c < p.n) {
+      float t = red[0][q2][e];
+#pragma unroll
+      for (int l = 1; l < 16; ++l) t += red[l][q2][e];
+      p.stats[((long)rt * 2 + (e >> 2)) * p.n + c] = t;
+    }
+  }
+}
+// second pass of a split-K launch (with or without the statistics)
+template <typename Tag>
+static inline void launch_splitk_epilogue(const GemmP& p, hipStream_t st) {
+  if (p.stats) {
+    hipLaunchKernelGGL(splitk_epilogue_stats_kernel<Tag>, dim3(p.m / p.stat_rows, (p.n + 63) / 64), dim3(256), 0, st, p);
+    return;
+  }
+  long blocks = ((long)p.m * (p.n >> 2) + 255) / 256;
+  if (blocks > 2048) blocks = 2048;
+  hipLaunchKernelGGL(splitk_epilogue_kernel<Tag>, dim3((unsigned)blocks), dim3(256), 0, st, p);
+}
+
 // ---- configurations: {BM, BN, BK, NST, WGM, WGN}
 template <typename Tag, int BM, int BN, int BK, int NST, int WGM, int WGN, int MODE>
 void launch_mode(const GemmP& p, hipStream_t st) {
@@ -1113,12 +1165,8 @@ void launch_mode(const GemmP& p, hipStream_t st) {
   static unsigned long long attr_done = 0;     // per kernel instance, one bit per device (see tt_lds_opt_in)
   tt_lds_opt_in((const void*)gemm_kernel<Tag, BM, BN, BK, NST, WGM, WGN, MODE>, (int)(lds + stat_lds), &attr_done);
   hipLaunchKernelGGL((gemm_kernel<Tag, BM, BN, BK, NST, WGM, WGN, MODE>), dim3(p.tiles_m * p.tiles_n * p.splitk),
-                     dim3(64 * WGM * WGN), p.stats ? lds + stat_lds : lds, st, p);
-  if (p.splitk > 1) {
-    long blocks = ((long)p.m * (p.n >> 2) + 255) / 256;
-    if (blocks > 2048) blocks = 2048;
-    hipLaunchKernelGGL(splitk_epilogue_kernel<Tag>, dim3((unsigned)blocks), dim3(256), 0, st, p);
-  }
+                     dim3(64 * WGM * WGN), (p.stats && p.splitk == 1) ? lds + stat_lds : lds, st, p);
+  if (p.splitk > 1) launch_splitk_epilogue<Tag>(p, st);
 }
 
 // LNOK: also instantiate the fused-LayerNorm variants (only the tile shapes the planner picks; gemm.hip keeps LayerNorm

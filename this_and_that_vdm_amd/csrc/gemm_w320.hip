@@ -794,11 +794,7 @@ static void launch_w320h_inst(GemmP& p, hipStream_t st) {
   static unsigned long long attr_done = 0;
   tt_lds_opt_in((const void*)gemm_w320h_kernel<Tag, MODE, LNROWS>, lds, &attr_done);
   hipLaunchKernelGGL((gemm_w320h_kernel<Tag, MODE, LNROWS>), dim3(p.tiles_m * p.tiles_n * p.splitk), dim3(512), lds, st, p);
-  if (p.splitk > 1) {                                        // second pass: the slabs summed in a fixed order + the full epilogue
-    long blocks = ((long)p.m * (p.n >> 2) + 255) / 256;
-    if (blocks > 2048) blocks = 2048;
-    hipLaunchKernelGGL(splitk_epilogue_kernel<Tag>, dim3((unsigned)blocks), dim3(256), 0, st, p);
-  }
+  if (p.splitk > 1) launch_splitk_epilogue<Tag>(p, st);      // second pass: the slabs summed in a fixed order + the full epilogue (+ the tile sums)
 }
 template <typename Tag>
 static void launch_w320h_tag(GemmP& p, hipStream_t st) {
