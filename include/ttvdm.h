@@ -110,15 +110,17 @@ typedef struct TtGemmArgs {
    * value in registers; tt_groupnorm_tiles turns the tile sums into the normalised tensor in ONE pass over it, without a
    * statistics pass.  Only routes and shapes for which tt_gemm_stats_rows(args) > 0 (TT_EUNSUPPORTED otherwise). */
   float* stats_out;
-  /* rows per statistics tile the CALLER asks for on the split-K routes (the coarse UNet levels: few output tiles, long K), where the
-   * sums are taken by the reduction kernel and any tile height works: pass a divisor of the GroupNorm segment (28-row images at the
-   * coarsest level).  Ignored on the other routes (their tile height is the kernel's); 0 = no statistics on a split-K route. */
-  int32_t stats_rows;
+  /* rows of the consumer's GroupNorm segment (one image: h*w; the frames of a video: frames*h*w), a hint that lets the route pick a
+   * statistics tile height R that divides it: the split-K routes (coarse UNet levels; the sums are taken by the reduction kernel, any
+   * height works) use the largest divisor of stats_seg up to 128; the tiled template falls back from its tile height (128) to the
+   * 32 / 64 rows of one wave row when only that divides stats_seg (448-row images, 1568-row videos).  0: the route's tile height. */
+  int32_t stats_seg;
 } TtGemmArgs;
 int tt_gemm(const TtGemmArgs* args, tt_stream_t stream);
-/* rows per statistics tile if tt_gemm can serve `args` with stats_out (the row height of the tile kernel the planner picks, or
- * args->stats_rows on a split-K route; m must be a multiple of it); 0: this problem's route has no statistics epilogue (GEGLU,
- * fp8 / fp32 / transposed outputs, the persistent kernels, a split-K route without stats_rows) -- leave stats_out NULL.  Host-only; call with ws / ws_bytes set as for tt_gemm (the plan depends on them). */
+/* rows per statistics tile R if tt_gemm can serve `args` with stats_out (see stats_seg; m must be a multiple of R -- on the tiled
+ * template a ragged last tile is fine, its rows beyond m add nothing); 0: this problem's route has no statistics epilogue (GEGLU,
+ * fp8 / fp32 / transposed outputs, the persistent kernels, a split-K route without stats_seg) -- leave stats_out NULL.  Host-only;
+ * call with ws / ws_bytes set as for tt_gemm (the plan depends on them). */
 int32_t tt_gemm_stats_rows(const TtGemmArgs* args);
 /* which tile configuration tt_gemm will use for this problem: cfg[0..6] = BM, BN, BK, ring stages, waves along M,
  * waves along N, split-K factor.  Lets a profiler name the kernel instance

@@ -919,7 +919,7 @@ def test_gemm_periodic_row_vector(ops, dtype, m, n, k, rows_per, mod):
 
 @pytest.mark.parametrize("dtype", DTYPES)
 @pytest.mark.parametrize("case", ["w320_conv", "w320_linear_res", "w320_tconv_blend", "w320h_conv", "tiled_linear", "tiled_tconv", "tiled_small",
-                                  "splitk_conv_l3", "splitk_tconv_l3", "splitk_conv_l2"])
+                                  "splitk_conv_l3", "splitk_tconv_l3", "splitk_conv_l2", "tiled_wave_rows", "tiled_wave_rows_ragged", "w320h_conv_64"])
 def test_gemm_output_statistics_and_groupnorm_from_tiles(ops, dtype, case):
     """TtGemmArgs.stats_out: per (row tile, column) sum / sum of squares of the STORED output, on every route that has the epilogue
     (256 x 320 and 128 x 320 big tiles, the tiled template), against sums over the stored tensor; then tt_groupnorm_tiles (one pass
@@ -933,8 +933,13 @@ def test_gemm_output_statistics_and_groupnorm_from_tiles(ops, dtype, case):
              tiled_small=dict(rows=1024, k=64, n=96, mode=0),
              # the split-K routes of the two coarsest levels: the reduction kernel takes the sums on tiles of the caller's height (28-row images)
              splitk_conv_l3=dict(nimg=28, h=4, w=7, cin=1280, n=1280, mode=1, res=True, per_image=True), splitk_tconv_l3=dict(nimg=28, h=4, w=7, cin=1280, n=1280, mode=2, blend=True),
-             splitk_conv_l2=dict(nimg=28, h=8, w=14, cin=1280, n=1280, mode=1))[case]
-    if case.startswith("splitk"):
+             splitk_conv_l2=dict(nimg=28, h=8, w=14, cin=1280, n=1280, mode=1),
+             # the tiled template with one statistics tile per wave row (32 rows): segments that are no whole number of 128-row tiles -- 448-row
+             # images of the second level; 1568-row videos of the third, whose 3136 rows also end in a ragged tile
+             w320h_conv_64=dict(nimg=28, h=16, w=28, cin=64, n=640, mode=1, per_image=True),      # 448-row images on 128-row tiles: one statistics tile per 64-row wave row
+             tiled_wave_rows=dict(rows=12544, k=128, n=640, mode=0, res=True, per_image=True),
+             tiled_wave_rows_ragged=dict(nimg=28, h=8, w=14, cin=128, n=1280, mode=2, blend=True))[case]
+    if case.startswith("splitk") or case == "tiled_wave_rows_ragged":
         frames = 14
     if dtype == torch.float32 and (case.startswith("w320") or case.startswith("splitk")):
         pytest.skip("the big-tile kernels and the split-K plans serve 16-bit storage")
@@ -966,12 +971,18 @@ def test_gemm_output_statistics_and_groupnorm_from_tiles(ops, dtype, case):
     st = getattr(out, "_tt_stats", None)
     assert st is not None, f"{case}: route without statistics epilogue"
     sbuf, r = st
-    if case.startswith("w320h"):
+    if case == "w320h_conv_64":
+        assert r == 64
+    elif case.startswith("w320h"):
         assert r == 128
     elif case.startswith("w320"):
         assert r == 256
     elif case.startswith("splitk"):
         assert r == {"splitk_conv_l3": 28, "splitk_tconv_l3": 98, "splitk_conv_l2": 112}[case]     # largest divisor <= 128 of the requested segment
+    elif case.startswith("tiled_wave_rows"):
+        assert r == 32 or (dtype == torch.float32 and seg % r == 0)          # (the fp32 template has its own tile shapes)
+    elif case.startswith("tiled") and dtype != torch.float32:
+        assert r == 128
     x = out.float()
     want = torch.stack([x.view(rows // r, r, n).sum(1), (x * x).view(rows // r, r, n).sum(1)], 1)
     torch.testing.assert_close(sbuf, want, rtol=2e-5, atol=2e-4)

@@ -30,7 +30,7 @@ class TtGemmArgs(C.Structure):
         ("ln_fold", C.c_int32), ("ln_eps", C.c_float), ("out_fp8", C.c_int32),
         ("rowvec_mod", C.c_int32),          # ABI 7: periodic row vector
         ("stats_out", C.c_void_p),          # ABI 8: per (row tile, column) sum / sum of squares of the stored output
-        ("stats_rows", C.c_int32),          # ... rows per tile requested on the split-K routes
+        ("stats_seg", C.c_int32),           # ... rows of the consumer's GroupNorm segment (hint for the statistics tile height)
     ]
 
 

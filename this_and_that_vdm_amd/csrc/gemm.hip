@@ -319,12 +319,24 @@ extern "C" int32_t tt_gemm_stats_rows(const TtGemmArgs* a) {
   // form) / residual / a blend with the residual itself -- not for the in-pass operand loads (gemm_kernel.h, `inpass`)
   int32_t cfg[7];
   if (tt_gemm_plan(a, cfg) != TT_OK) return 0;
-  if (cfg[6] != 1)                                                     // split-K: the reduction kernel takes the sums, on tiles of the caller's height
-    return (a->stats_rows > 0 && a->stats_rows <= 4096 && a->m % a->stats_rows == 0) ? a->stats_rows : 0;
+  const int seg = a->stats_seg;
+  if (cfg[6] != 1) {                                                   // split-K: the reduction kernel takes the sums, on tiles of any height:
+    if (seg <= 0) return 0;                                            // the largest divisor of the consumer's segment up to 128 rows
+    for (int r = seg < 128 ? seg : 128; r > 0; --r)
+      if (seg % r == 0) return a->m % r == 0 ? r : 0;
+    return 0;
+  }
   if (a->blend && !(a->blend == a->residual && a->ld_blend == a->ld_res)) return 0;
   if (a->rowvec && a->rowvec_rows < 32 && !(a->rowvec_rows == 1 && a->rowvec_mod == 2)) return 0;
   if (cfg[0] > 128 && cfg[1] != 320 && a->residual) return 0;         // 256-row tiles of the tiled template read the residual in-pass
-  return a->m % cfg[0] == 0 ? cfg[0] : 0;
+  if (cfg[1] == 320 || cfg[3] == 0) {                                  // the big-tile kernels: whole tiles; the 128-row one also the 64 rows of a wave row
+    if (a->m % cfg[0]) return 0;
+    return (cfg[0] == 128 && seg > 0 && seg % 128 && seg % 64 == 0) ? 64 : cfg[0];
+  }
+  // the tiled template: whole tiles (BM rows) if they divide the segment (or no hint), else the rows of one wave row (BM / WGM: 32 or 64)
+  const int wave_rows = cfg[0] / cfg[4];
+  const int r = (seg <= 0 || seg % cfg[0] == 0) ? cfg[0] : (seg % wave_rows == 0 ? wave_rows : cfg[0]);
+  return a->m % r == 0 ? r : 0;
 }
 
 extern "C" size_t tt_gemm_ws_bytes(const TtGemmArgs* a) {
@@ -376,7 +388,7 @@ extern "C" int tt_gemm(const TtGemmArgs* a, tt_stream_t stream) {
   const int es = a->dtype == TT_F32 ? 4 : 2;         // bytes per stored element
   p.out = (char*)a->out; p.ldo = a->ldo; p.out_f32 = a->dtype == TT_F32 ? 0 : a->out_f32;   // TT_F32 stores fp32 anyway
   p.out_col_hw = a->out_col_hw; p.out_col_hwp = a->out_col_hwp;
-  p.ln_fold = a->ln_fold; p.ln_eps = a->ln_eps; p.out_fp8 = a->out_fp8; p.stats = a->stats_out; p.stat_rows = a->stats_rows;
+  p.ln_fold = a->ln_fold; p.ln_eps = a->ln_eps; p.out_fp8 = a->out_fp8; p.stats = a->stats_out; p.stat_rows = a->stats_out ? tt_gemm_stats_rows(a) : 0;
   if (p.mode == 1) {
     if (p.nimg <= 0 || p.hin <= 0 || p.win <= 0 || p.hout <= 0 || p.wout <= 0 || p.stride < 1)
       TT_FAIL(TT_EINVAL, "tt_gemm: conv geometry");

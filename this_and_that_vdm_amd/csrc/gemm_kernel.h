@@ -800,10 +800,11 @@ void gemm_kernel(const GemmP p) {
                       const quad_t packed = f32_to_quad<Tag>(v);
                       if constexpr (ES == 2) st64(r_out, ok ? (int)(((long)gm * p.ldo + gn) * ES) : kInv, packed.x, packed.y);
                       else stq<Tag>(r_out, ok ? (int)(((long)gm * p.ldo + gn) * ES) : kInv, v);
-                      if constexpr (STATS) {               // (rows >= m never occur: the host grants stats only for m % BM == 0)
+                      if constexpr (STATS) {               // (rows >= m of a ragged last tile add nothing)
                         float sv[4];
                         quad_to_f32<Tag>(packed, sv);
-                        *(float4*)(ebuf + strip_off(r, qq, q_per_row)) = make_float4(sv[0], sv[1], sv[2], sv[3]);
+                        const bool live = gm < p.m;
+                        *(float4*)(ebuf + strip_off(r, qq, q_per_row)) = make_float4(live ? sv[0] : 0.f, live ? sv[1] : 0.f, live ? sv[2] : 0.f, live ? sv[3] : 0.f);
                       }
                     }
                   }
@@ -824,20 +825,32 @@ void gemm_kernel(const GemmP p) {
       else if (MODE == 0 && ES == 2 && p.out_fp8) {          // Q | K and V^T of the fp8 attention path (linear, no residual)
         if constexpr (MODE == 0 && ES == 2) run(no, no, yes, no);
       } else { if (kstats) run(no, no, no, yes); else run(no, no, no, no); }
-      if (kstats) {                                        // the waves of one tile column, wave rows in order
+      if (kstats) {
         __syncthreads();
         const float* st0 = (const float*)(smem + STAT_OFF);
-        for (int c = tid; c < BN; c += NT) {
-          const int wcc = c / WTN, col = c - wcc * WTN;
-          float a = 0.f, b = 0.f;
+        if (p.stat_rows == BM) {                             // one statistics tile per output tile: the waves of one tile column, wave rows in order
+          for (int c = tid; c < BN; c += NT) {
+            const int wcc = c / WTN, col = c - wcc * WTN;
+            float a = 0.f, b = 0.f;
 #pragma unroll
-          for (int w = 0; w < WGM; ++w) {
-            const float* row = st0 + (w * WGN + wcc) * (2 * WTN);
-            a += row[col]; b += row[WTN + col];
+            for (int w = 0; w < WGM; ++w) {
+              const float* row = st0 + (w * WGN + wcc) * (2 * WTN);
+              a += row[col]; b += row[WTN + col];
+            }
+            if (n0 + c < p.n) {
+              p.stats[((long)tile_m * 2) * p.n + n0 + c] = a;
+              p.stats[((long)tile_m * 2 + 1) * p.n + n0 + c] = b;
+            }
           }
-          if (n0 + c < p.n) {
-            p.stats[((long)tile_m * 2) * p.n + n0 + c] = a;
-            p.stats[((long)tile_m * 2 + 1) * p.n + n0 + c] = b;
+        } else {                                             // one per wave row (WTM rows; tt_gemm_stats_rows): segments that are no whole number of tiles
+          for (int c = tid; c < BN * WGM; c += NT) {
+            const int w = c / BN, cc = c - w * BN, wcc = cc / WTN, col = cc - wcc * WTN;
+            const float* row = st0 + (w * WGN + wcc) * (2 * WTN);
+            const long srow = (long)tile_m * WGM + w;
+            if (n0 + cc < p.n && srow * WTM < p.m) {
+              p.stats[(srow * 2) * p.n + n0 + cc] = row[col];
+              p.stats[(srow * 2 + 1) * p.n + n0 + cc] = row[WTN + col];
+            }
           }
         }
       }

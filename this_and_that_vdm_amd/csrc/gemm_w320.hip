@@ -207,17 +207,21 @@ __device__ __forceinline__ void w3_epilogue_dispatch(const GemmP& p, const f32x1
 
 // ---- GemmP.stats, tile level: the waves' staging rows ([wave][2][160] floats at `st0`) of the waves that share a column half,
 // added in a fixed order; thread c < 320 finishes column c.  `nw` waves per column half: wave index of (k, half) = wave_of(k, half).
-template <typename F> __device__ __forceinline__ void w3_stats_tile(const GemmP& p, const float* st0, int tid, int tile_m, int n0, int nw, F wave_of) {
+// `parts` statistics tiles per output tile (1, or 2 on the 128-row kernel when GemmP.stat_rows asks for the 64 rows of one wave row: 448-row images).
+template <typename F> __device__ __forceinline__ void w3_stats_tile(const GemmP& p, const float* st0, int tid, int tile_m, int n0, int nw, F wave_of, int parts = 1) {
   __syncthreads();
   if (tid < 320) {
-    const int half = tid >= 160 ? 1 : 0, col = tid - half * 160;
-    float a = 0.f, b = 0.f;
-    for (int k = 0; k < nw; ++k) {
-      const float* row = st0 + wave_of(k, half) * 320;
-      a += row[col]; b += row[160 + col];
+    const int half = tid >= 160 ? 1 : 0, col = tid - half * 160, per = nw / parts;
+    for (int part = 0; part < parts; ++part) {
+      float a = 0.f, b = 0.f;
+      for (int k = part * per; k < (part + 1) * per; ++k) {
+        const float* row = st0 + wave_of(k, half) * 320;
+        a += row[col]; b += row[160 + col];
+      }
+      const long srow = (long)tile_m * parts + part;
+      p.stats[(srow * 2) * p.n + n0 + tid] = a;
+      p.stats[(srow * 2 + 1) * p.n + n0 + tid] = b;
     }
-    p.stats[((long)tile_m * 2) * p.n + n0 + tid] = a;
-    p.stats[((long)tile_m * 2 + 1) * p.n + n0 + tid] = b;
   }
 }
 
@@ -762,7 +766,7 @@ __global__ __launch_bounds__(512, 2) void gemm_w320h_kernel(const GemmP p) {
   if (grp == 0) w3_epilogue_dispatch<Tag, 1, true>(p, &acc[0], &rs[0], ebuf, mb, ncol0, lane, acc[1], xbuf, pbuf, sst + wid * 320);
   else w3_epilogue_dispatch<Tag, 1, true>(p, &acc[1], &rs[1], ebuf, mb + 32, ncol0, lane, acc[0], xbuf, pbuf, sst + wid * 320);
   // wid = grp * 4 + wr * 2 + wc: the four waves (K half, row half) of a column half, rows in order
-  if (p.stats) w3_stats_tile(p, sst, tid, tile_m, n0, 4, [](int k, int half) { return (k & 1) * 4 + (k >> 1) * 2 + half; });
+  if (p.stats) w3_stats_tile(p, sst, tid, tile_m, n0, 4, [](int k, int half) { return (k & 1) * 4 + (k >> 1) * 2 + half; }, p.stat_rows == 64 ? 2 : 1);
 }
 
 template <typename Tag, int MODE, int LNROWS>

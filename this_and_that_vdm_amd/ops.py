@@ -33,14 +33,6 @@ def _prof_end(start, name, flops, shape=None):
         PROFILE.append((name, flops, start, e, shape))
 
 
-def _split_stat_rows(seg: int) -> int:
-    """largest divisor of a GroupNorm segment that is <= 128 rows (28 -> 28, 112 -> 112, 392 -> 98, 1568 -> 112)"""
-    for r in range(min(seg, 128), 0, -1):
-        if seg % r == 0:
-            return r
-    return 0
-
-
 _WS = {}
 _WS_RETIRED = []          # outgrown buffers stay allocated: a captured hipGraph may still hold their address
 WS_FLOOR_BYTES = 64 << 20
@@ -155,7 +147,7 @@ def gemm(a0: torch.Tensor, w: torch.Tensor, *, a1: Optional[torch.Tensor] = None
     # (only for outputs up to the finest level's size at 256x448: the statistics epilogue costs 1-2.6 us PER TILE of a workgroup, so a
     # launch that walks 3-4 tiles per CU -- 512x896 latents -- pays more than the consumer's saved pass: 107.5 -> 108.5 ms/step, one call)
     if stats and GN_TILES and g.m * n <= GN_TILES_MAX_ELEMS:
-        g.stats_rows = _split_stat_rows(int(stats)) if GN_TILES_SPLITK else 0     # (honoured on the split-K routes only: their reduction kernel takes the sums)
+        g.stats_seg = int(stats) if GN_TILES_SEG else 0        # (lets the split-K routes and the tiled template pick a tile height that divides the segment)
         srows = lib.tt_gemm_stats_rows(C.byref(g))
         if srows > 0 and lib.tt_groupnorm_tiles_supported(int(stats), n, srows, g.dtype):
             sbuf = torch.empty(((g.m + srows - 1) // srows, 2, n), dtype=torch.float32, device=a0.device)
@@ -313,7 +305,7 @@ GN_CROSS_MAX_ROWS = int(os.environ.get("TT_GN_CROSS_ROWS", "0"))
 # GroupNorm from the producer's tile sums (tt_gemm stats_out -> tt_groupnorm_tiles): on by default, TT_GN_TILES=0 keeps every
 # GroupNorm on the statistics-pass kernels (A/B)
 GN_TILES = os.environ.get("TT_GN_TILES", "1") != "0"
-GN_TILES_SPLITK = os.environ.get("TT_GN_TILES_SPLITK", "1") != "0"       # ... also from the reduction kernel of the split-K routes (coarse levels)
+GN_TILES_SEG = os.environ.get("TT_GN_TILES_SEG", "1") != "0"       # ... also on the split-K routes (coarse levels) and with per-wave-row sums of the tiled template (A/B)
 GN_TILES_MAX_ELEMS = int(os.environ.get("TT_GN_TILES_MAX_ELEMS", str(17 << 20)))
 _GN_EMULATE = os.environ.get("TT_GN_EMULATE", "0") == "1"
 _GN_EMU_CACHE = {}
