@@ -982,7 +982,7 @@ def test_gemm_output_statistics_and_groupnorm_from_tiles(ops, dtype, case):
     elif case.startswith("tiled_wave_rows"):
         assert r == 32 or (dtype == torch.float32 and seg % r == 0)          # (the fp32 template has its own tile shapes)
     elif case.startswith("tiled") and dtype != torch.float32:
-        assert r == 128
+        assert r in (64, 128)                                 # whole tiles of the planner's tile shape
     x = out.float()
     want = torch.stack([x.view(rows // r, r, n).sum(1), (x * x).view(rows // r, r, n).sum(1)], 1)
     torch.testing.assert_close(sbuf, want, rtol=2e-5, atol=2e-4)

@@ -116,6 +116,14 @@ Plan make_plan(int m, int n, long ktot, bool allow_split, bool wide_ok = true, b
     // in isolation: FF2 at 3136 rows 690 -> 791 TFLOP/s, K = 1280 509 -> 556, the 3x3 conv 792 -> 848 (tools/gemm_bench.py 16 20), and
     // slower in the step: 31.19 / 31.23 -> 31.48 / 31.51 ms, restricted to K >= 4096 30.83 / 31.08 -> 31.26 / 31.17: a double buffer
     // has one K step of prefetch where the 4-deep ring has three.  Opt-in: TT_GEMM_DEEP=2.)
+    // Short-K linears that leave half of the CUs without a 128 x 128 tile (the half-row output projections of the cross-attentions at the
+    // third level, everything K = C at the coarsest one) on 64 x 64 tiles, two blocks per CU, all resident at once: faster on warm operands
+    // (tools/small_gemm_sweep.py, us in a graph of ten launches: 1568 x 1280 x 1280 16.8 -> 12.3, 784 rows 16.6 -> 11.3, 392 rows 13.7 -> 10.0),
+    // NOT in the step, where every weight comes from HBM once and 64-row tiles fetch it twice as often: 29.06 / 29.18 -> 29.10 / 29.10 ms
+    // (one call, interleaved).  Opt-in: TT_GEMM_SMALL64=1.
+    static int small64 = -1;
+    if (small64 < 0) { const char* e = getenv("TT_GEMM_SMALL64"); small64 = e ? atoi(e) : 0; }
+    if (small64 && mode0 && ktot <= 2048 && (long)ceil_div(m, 64) * ceil_div(n, 64) <= 512) { pl.cfg = 2; return pl; }
     pl.cfg = (deep == 2 && k128) ? 20 : 16;
     long s = allow_split ? 256 / b128 : 1;
     if (s > kt / 8) s = kt / 8;

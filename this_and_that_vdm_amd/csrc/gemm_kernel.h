@@ -1117,18 +1117,18 @@ __global__ __launch_bounds__(256) void splitk_epilogue_kernel(const GemmP p) {
 }
 
 // ... the same with the GroupNorm tile sums of the output (GemmP.stats; the split-K routes of the two coarsest UNet levels): block (row tile of
-// p.stat_rows rows, chunk of 64 columns), thread (column quad, one of sixteen row lanes) walks its rows (two of a 28-row image), adds what it
-// stores; the row lanes meet in LDS in a fixed order.  The caller picks the tile height (any divisor of its GroupNorm segment).
+// p.stat_rows rows, chunk of 32 columns), thread (column quad, one of 32 row lanes) walks its rows (one of a 28-row image, four of a 98- or
+// 112-row tile), adds what it stores; the row lanes meet in LDS in a fixed order.  The caller picks the tile height (tt_gemm_stats_rows).
 template <typename Tag>
 __global__ __launch_bounds__(256) void splitk_epilogue_stats_kernel(const GemmP p) {
-  __shared__ float red[16][16][8];
+  __shared__ float red[32][8][8];
   kernarg_touch<sizeof(GemmP)>();
   const int R = p.stat_rows, rt = blockIdx.x, tid = threadIdx.x;
-  const int qd = tid & 15, rl = tid >> 4;
-  const int gn = (int)blockIdx.y * 64 + qd * 4;
+  const int qd = tid & 7, rl = tid >> 3;
+  const int gn = (int)blockIdx.y * 32 + qd * 4;
   float cs[4] = {0.f, 0.f, 0.f, 0.f}, cq[4] = {0.f, 0.f, 0.f, 0.f};
   if (gn < p.n) {
-    for (int r = rl; r < R; r += 16) {
+    for (int r = rl; r < R; r += 32) {
       const int gm = rt * R + r;                              // < m: m is a multiple of R (tt_gemm_stats_rows)
       float4 a = *(const float4*)(p.ws + (long)gm * p.n + gn);
       for (int s2 = 1; s2 < p.splitk; ++s2) {
@@ -1144,12 +1144,12 @@ __global__ __launch_bounds__(256) void splitk_epilogue_stats_kernel(const GemmP 
 #pragma unroll
   for (int e = 0; e < 4; ++e) { red[rl][qd][e] = cs[e]; red[rl][qd][4 + e] = cq[e]; }
   __syncthreads();
-  if (tid < 128) {                                            // thread (column quad, one of its eight sums): the sixteen row lanes in order
-    const int q2 = tid >> 3, e = tid & 7, c = (int)blockIdx.y * 64 + q2 * 4 + (e & 3);
+  if (tid < 64) {                                             // thread (column quad, one of its eight sums): the 32 row lanes in order
+    const int q2 = tid >> 3, e = tid & 7, c = (int)blockIdx.y * 32 + q2 * 4 + (e & 3);
     if (c < p.n) {
       float t = red[0][q2][e];
 #pragma unroll
-      for (int l = 1; l < 16; ++l) t += red[l][q2][e];
+      for (int l = 1; l < 32; ++l) t += red[l][q2][e];
       p.stats[((long)rt * 2 + (e >> 2)) * p.n + c] = t;
     }
   }
@@ -1158,7 +1158,7 @@ __global__ __launch_bounds__(256) void splitk_epilogue_stats_kernel(const GemmP 
 template <typename Tag>
 static inline void launch_splitk_epilogue(const GemmP& p, hipStream_t st) {
   if (p.stats) {
-    hipLaunchKernelGGL(splitk_epilogue_stats_kernel<Tag>, dim3(p.m / p.stat_rows, (p.n + 63) / 64), dim3(256), 0, st, p);
+    hipLaunchKernelGGL(splitk_epilogue_stats_kernel<Tag>, dim3(p.m / p.stat_rows, (p.n + 31) / 32), dim3(256), 0, st, p);
     return;
   }
   long blocks = ((long)p.m * (p.n >> 2) + 255) / 256;
