@@ -115,8 +115,23 @@ typedef struct TtGemmArgs {
    * height works) use the largest divisor of stats_seg up to 128; the tiled template falls back from its tile height (128) to the
    * 32 / 64 rows of one wave row when only that divides stats_seg (448-row images, 1568-row videos).  0: the route's tile height. */
   int32_t stats_seg;
+  /* ABI 9.  gn_out != NULL: the launch ALSO writes act(GroupNorm_32(out)) to gn_out (same storage type, row stride ld_gn elements), with
+   * statistics per segment of stats_seg output rows (one image, or the frames of a video), gamma / beta fp32 [n], SiLU when gn_silu != 0
+   * -- the GroupNorm that reads this launch's output (ResnetBlock2D.norm2 after conv1, TemporalResnetBlock.norm1 / norm2 --
+   * unet_3d_blocks.py:1891-2316 via diffusers ResnetBlock2D / TemporalResnetBlock).  Only where the launch ends in the split-K
+   * reduction pass anyway (the two coarsest UNet levels: 784 / 3136 rows), which then owns a whole (segment, group) per block: it sums
+   * the fp32 slabs, applies the epilogue, stores `out`, and normalises the stored values from registers -- one launch instead of the
+   * reduction plus a GroupNorm launch.  tt_gemm_gn_fused(args) != 0 says whether `args` qualifies (TT_EUNSUPPORTED otherwise);
+   * exclusive with stats_out. */
+  void* gn_out; int64_t ld_gn;
+  const float* gn_gamma; const float* gn_beta;
+  float gn_eps; int32_t gn_silu;
 } TtGemmArgs;
 int tt_gemm(const TtGemmArgs* args, tt_stream_t stream);
+/* 1 if tt_gemm serves `args` with gn_out (a split-K plan, 16-bit storage, stats_seg rows per segment dividing m and short enough for one
+ * block -- up to 816 rows at 1280 channels, 1632 at 640 --, n / 32 channels per group a multiple of 4, plain row-major 16-bit output), else 0.
+ * Host-only; set ws / ws_bytes as for tt_gemm. */
+int32_t tt_gemm_gn_fused(const TtGemmArgs* args);
 /* rows per statistics tile R if tt_gemm can serve `args` with stats_out (see stats_seg; m must be a multiple of R -- on the tiled
  * template a ragged last tile is fine, its rows beyond m add nothing); 0: this problem's route has no statistics epilogue (GEGLU,
  * fp8 / fp32 / transposed outputs, the persistent kernels, a split-K route without stats_seg) -- leave stats_out NULL.  Host-only;

@@ -917,6 +917,67 @@ def test_gemm_periodic_row_vector(ops, dtype, m, n, k, rows_per, mod):
         ops.gemm(ad, wd, bias=bd, rowvec=rd[:1], rowvec_rows=rows_per, rowvec_mod=mod)          # fewer vectors than the period
 
 
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
+@pytest.mark.parametrize("case", ["conv_l3_per_image", "tconv_l3_cross_frame_film", "conv_l3_cross_frame_res", "conv_l2_per_image", "linear_l3_c640"])
+def test_gemm_groupnorm_inside_the_splitk_reduction(ops, dtype, case):
+    """TtGemmArgs.gn_out (ABI 9): on the split-K plans of the two coarsest levels the reduction pass also writes SiLU(GroupNorm(out)) --
+    per image (28 / 112 rows) and across the frames of a video (392 rows).  The plain output must not change (bit for bit), the
+    normalised tensor must match torch group_norm of the STORED output and the statistics-pass kernels within storage rounding, be
+    bit-reproducible, and ops.groupnorm must hand it out only for the parameters it was computed with."""
+    g = dict(conv_l3_per_image=dict(nimg=28, h=4, w=7, cin=1280, n=1280, mode=1, film=True, fpg=1),
+             tconv_l3_cross_frame_film=dict(nimg=28, h=4, w=7, cin=1280, n=1280, mode=2, film=True, fpg=14),
+             conv_l3_cross_frame_res=dict(nimg=28, h=4, w=7, cin=1280, n=1280, mode=1, res=True, fpg=14),
+             conv_l2_per_image=dict(nimg=28, h=8, w=14, cin=1280, n=1280, mode=1, film=True, fpg=1),
+             linear_l3_c640=dict(nimg=28, h=4, w=7, cin=10240, n=640, mode=0, res=True, fpg=1))[case]
+    frames, mode, n, fpg = 14, g["mode"], g["n"], g["fpg"]
+    hw, k = g["h"] * g["w"], g["cin"]
+    nimg = g["nimg"]
+    rows = nimg * hw
+    taps = {0: 1, 1: 9, 2: 3}[mode]
+    a = rnd(rows, k, dtype=dtype, seed=1).cuda()
+    w = rnd(n, taps * k, dtype=dtype, seed=2, scale=(taps * k) ** -0.5).cuda()
+    kw = dict(bias=(rnd(n, dtype=torch.float32, seed=3) + 0.5).cuda(), mode=mode)
+    if mode == 1:
+        kw["conv"] = (nimg, g["h"], g["w"], g["h"], g["w"], 1, 0)
+    if mode == 2:
+        kw["tconv"] = (frames, hw)
+    if g.get("film"):
+        kw.update(rowvec=rnd(2, n, dtype=torch.float32, seed=4).cuda(), rowvec_rows=frames * hw)
+    if g.get("res"):
+        kw["residual"] = rnd(rows, n, dtype=dtype, seed=5).cuda()
+    gamma, beta = (rnd(n, dtype=torch.float32, seed=6) * 0.2 + 1).cuda(), (rnd(n, dtype=torch.float32, seed=7) * 0.3).cuda()
+    seg = fpg * hw
+    plain = ops.gemm(a, w, **kw)
+    y_old = ops.groupnorm(plain, None, nimg, hw, fpg, gamma, beta, 1e-5, True)            # the statistics-pass kernels
+    out = ops.gemm(a, w, stats=seg, gn=(gamma, beta, 1e-5, True), **kw)
+    assert torch.equal(out, plain), "the fused GroupNorm must not change the output"
+    fz = getattr(out, "_tt_gn", None)
+    assert fz is not None, f"{case}: no split-K reduction pass on this plan"
+    y = ops.groupnorm(out, None, nimg, hw, fpg, gamma, beta, 1e-5, True)
+    assert y.data_ptr() == fz[0].data_ptr(), "groupnorm() must hand out the producer's result"
+    x = out.float()
+    ref = F.silu(F.group_norm(x.view(nimg // fpg, seg, n).permute(0, 2, 1), 32, gamma, beta, 1e-5)).permute(0, 2, 1).reshape(rows, n)
+    close(y, ref.cpu(), dtype, scale=2.0)
+    tol = TOL[dtype]
+    torch.testing.assert_close(y.float(), y_old.float(), rtol=tol["rtol"], atol=tol["atol"])
+    again = ops.gemm(a, w, stats=seg, gn=(gamma, beta, 1e-5, True), **kw)
+    assert torch.equal(again._tt_gn[0], y), "bit-reproducible"
+    # other parameters than the ones it was computed with: not handed out (the generic routes run)
+    y2 = ops.groupnorm(out, None, nimg, hw, fpg, gamma, beta, 1e-5, False)
+    assert y2.data_ptr() != fz[0].data_ptr()
+    ref2 = F.group_norm(x.view(nimg // fpg, seg, n).permute(0, 2, 1), 32, gamma, beta, 1e-5).permute(0, 2, 1).reshape(rows, n)
+    close(y2, ref2.cpu(), dtype, scale=2.0)
+    if fpg == 1:
+        y3 = ops.groupnorm(out, None, nimg, hw, frames, gamma, beta, 1e-5, True)         # another segment length
+        assert y3.data_ptr() != fz[0].data_ptr()
+    # an in-place overwrite drops the stale result
+    ops.gemm(a, w, out=out, **kw)
+    assert not hasattr(out, "_tt_gn")
+    # a plan without a reduction pass ignores `gn` (and keeps the statistics route)
+    big = ops.gemm(rnd(50176, 64, dtype=dtype, seed=8).cuda(), rnd(320, 64, dtype=dtype, seed=9).cuda(), stats=1792, gn=(gamma[:320].contiguous(), beta[:320].contiguous(), 1e-5, True))
+    assert not hasattr(big, "_tt_gn")
+
+
 @pytest.mark.parametrize("dtype", DTYPES)
 @pytest.mark.parametrize("case", ["w320_conv", "w320_linear_res", "w320_tconv_blend", "w320h_conv", "tiled_linear", "tiled_tconv", "tiled_small",
                                   "splitk_conv_l3", "splitk_tconv_l3", "splitk_conv_l2", "tiled_wave_rows", "tiled_wave_rows_ragged", "w320h_conv_64"])

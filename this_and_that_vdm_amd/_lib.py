@@ -31,6 +31,8 @@ class TtGemmArgs(C.Structure):
         ("rowvec_mod", C.c_int32),          # ABI 7: periodic row vector
         ("stats_out", C.c_void_p),          # ABI 8: per (row tile, column) sum / sum of squares of the stored output
         ("stats_seg", C.c_int32),           # ... rows of the consumer's GroupNorm segment (hint for the statistics tile height)
+        ("gn_out", C.c_void_p), ("ld_gn", C.c_int64), ("gn_gamma", C.c_void_p), ("gn_beta", C.c_void_p),      # ABI 9: GroupNorm in the split-K reduction
+        ("gn_eps", C.c_float), ("gn_silu", C.c_int32),
     ]
 
 
@@ -86,6 +88,7 @@ SIGNATURES = {
     "tt_groupnorm_tiles_supported": (C.c_int, [_i32, _i32, _i32, _i32]),
     "tt_groupnorm_tiles": (C.c_int, [_vp, _i32, _vp, _i32, _i32, _i32, _vp, _vp, _f32, _i32, _vp, _i64, _i32, _vp]),
     "tt_gemm_stats_rows": (C.c_int32, [C.POINTER(TtGemmArgs)]),
+    "tt_gemm_gn_fused": (C.c_int32, [C.POINTER(TtGemmArgs)]),
     "tt_layernorm": (C.c_int, [_vp, _i64, _i32, _i32, _vp, _vp, _f32, _vp, _i32, _i32, _vp, _vp, _i64, _i32, _vp]),
     "tt_small_linear": (C.c_int, [_vp, _i64, _i32, _i32, _vp, _i64, _i32, _vp, _i32, _i32, _i32, _vp, _i64, _i32, _vp]),
     "tt_timestep_embedding": (C.c_int, [_vp, _i32, _i32, _vp, _i64, _vp]),
@@ -128,7 +131,7 @@ def load():
     for name, (res, args) in SIGNATURES.items():
         fn = getattr(lib, name)          # AttributeError here == ABI mismatch with include/ttvdm.h
         fn.restype, fn.argtypes = res, args
-    if lib.tt_abi_version() != 8:
+    if lib.tt_abi_version() != 9:
         raise RuntimeError("libttvdm.so ABI version mismatch")
     _lib = lib
     return lib

@@ -347,6 +347,18 @@ extern "C" int32_t tt_gemm_stats_rows(const TtGemmArgs* a) {
   return a->m % r == 0 ? r : 0;
 }
 
+// GroupNorm inside the split-K reduction (TtGemmArgs.gn_out): see include/ttvdm.h
+extern "C" int32_t tt_gemm_gn_fused(const TtGemmArgs* a) {
+  if (!a || a->m <= 0 || a->n <= 0 || a->dtype == TT_F32) return 0;
+  if (a->geglu || a->out_fp8 || a->out_f32 || a->out_col_hw > 0 || a->stats_out) return 0;
+  const int seg = a->stats_seg;
+  if (seg <= 0 || a->m % seg || (a->n & 127)) return 0;               // 32 groups of a whole number of column quads
+  if (pp_ok(a) || pp_split_rows(a) || sq320_ok(a)) return 0;
+  int32_t cfg[7];
+  if (tt_gemm_plan(a, cfg) != TT_OK || cfg[6] <= 1) return 0;         // only where a reduction pass runs anyway
+  return splitk_gn_rows(seg, a->n, nullptr) > 0 ? 1 : 0;
+}
+
 extern "C" size_t tt_gemm_ws_bytes(const TtGemmArgs* a) {
   if (!a || a->m <= 0 || a->n <= 0) return 0;
   if (pp_ok(a)) return 0;
@@ -374,6 +386,10 @@ extern "C" int tt_gemm(const TtGemmArgs* a, tt_stream_t stream) {
   if (a->geglu && ((a->n & 15) || a->residual || a->blend || a->rowvec || a->out_f32 || a->out_col_hw))
     TT_FAIL(TT_EINVAL, "tt_gemm: geglu needs n %% 16 == 0 and no other epilogue terms");
   if (a->rowvec && a->rowvec_rows <= 0) TT_FAIL(TT_EINVAL, "tt_gemm: rowvec_rows");
+  if (a->gn_out) {
+    if (!a->gn_gamma || !a->gn_beta || (a->ld_gn & 3) || ((size_t)a->gn_out & 7)) TT_FAIL(TT_EINVAL, "tt_gemm: gn_out needs gn_gamma, gn_beta, ld_gn %% 4 == 0 and an 8-byte aligned pointer");
+    if (!tt_gemm_gn_fused(a)) TT_FAIL(TT_EUNSUPPORTED, "tt_gemm: gn_out on a problem without a split-K reduction pass (tt_gemm_gn_fused(args) == 0)");
+  }
   if (a->stats_out && tt_gemm_stats_rows(a) == 0)
     TT_FAIL(TT_EUNSUPPORTED, "tt_gemm: stats_out on a route without a statistics epilogue (tt_gemm_stats_rows(args) == 0)");
   if (a->rowvec_mod < 0 || (a->rowvec_mod > 0 && !a->rowvec)) TT_FAIL(TT_EINVAL, "tt_gemm: rowvec_mod %d (>= 0, needs rowvec)", a->rowvec_mod);
@@ -396,7 +412,8 @@ extern "C" int tt_gemm(const TtGemmArgs* a, tt_stream_t stream) {
   const int es = a->dtype == TT_F32 ? 4 : 2;         // bytes per stored element
   p.out = (char*)a->out; p.ldo = a->ldo; p.out_f32 = a->dtype == TT_F32 ? 0 : a->out_f32;   // TT_F32 stores fp32 anyway
   p.out_col_hw = a->out_col_hw; p.out_col_hwp = a->out_col_hwp;
-  p.ln_fold = a->ln_fold; p.ln_eps = a->ln_eps; p.out_fp8 = a->out_fp8; p.stats = a->stats_out; p.stat_rows = a->stats_out ? tt_gemm_stats_rows(a) : 0;
+  p.ln_fold = a->ln_fold; p.ln_eps = a->ln_eps; p.out_fp8 = a->out_fp8; p.stats = a->stats_out; p.stat_rows = a->gn_out ? a->stats_seg : (a->stats_out ? tt_gemm_stats_rows(a) : 0);
+  p.gn_out = (char*)a->gn_out; p.ld_gn = a->ld_gn; p.gn_gamma = a->gn_gamma; p.gn_beta = a->gn_beta; p.gn_eps = a->gn_eps; p.gn_silu = a->gn_silu;
   if (p.mode == 1) {
     if (p.nimg <= 0 || p.hin <= 0 || p.win <= 0 || p.hout <= 0 || p.wout <= 0 || p.stride < 1)
       TT_FAIL(TT_EINVAL, "tt_gemm: conv geometry");

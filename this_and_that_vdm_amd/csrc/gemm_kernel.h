@@ -51,7 +51,9 @@ struct GemmP {
   int ln_fold; float ln_eps;        // fused LayerNorm of the A rows (1) / W rows (2): see gemm_kernel, MODE 3 / 4
   int out_fp8;                      // store e4m3 bytes (operands of the fp8 attention path) instead of 16-bit values
   float* stats;                     // != NULL: per (row tile, column) sum and sum of squares of the stored output (TtGemmArgs.stats_out)
-  int stat_rows;                    // split-K launches: rows per statistics tile of the reduction kernel (TtGemmArgs.stats_rows)
+  int stat_rows;                    // rows per statistics tile (tt_gemm_stats_rows); with gn_out: rows per GroupNorm segment
+  char* gn_out; long ld_gn;         // != NULL: the split-K reduction also writes act(GroupNorm(out)) (TtGemmArgs.gn_out)
+  const float* gn_gamma; const float* gn_beta; float gn_eps; int gn_silu;
   // launch-uniform divisors of the tiled template as multiply-shift pairs (fill_fastdivs, called by launch_cfg)
   FastDiv fd_splitk, fd_per_group, fd_group_m, fd_last_rows, fd_per_tap, fd_hwo, fd_wout, fd_hw, fd_frames, fd_rv_rows, fd_rv_mod;
 };
@@ -181,32 +183,44 @@ template <> __device__ __forceinline__ uint2 zero_quad<bf16_tag>() { return make
 template <> __device__ __forceinline__ uint2 zero_quad<f16_tag>() { return make_uint2(0, 0); }
 template <> __device__ __forceinline__ uint4 zero_quad<f32_tag>() { return make_uint4(0, 0, 0, 0); }
 
-// ---- epilogue on 4 consecutive output columns (gn .. gn+3) of row gm
+// ---- epilogue on 4 consecutive output columns (gn .. gn+3) of row gm, in two halves: epi_load requests the operands (bias, row vector,
+// residual, blend), epi_finish does the arithmetic and stores.  The split-K reduction kernels request the operands of all their rows BEFORE
+// they sum the slabs, so one memory round trip covers slabs and operands (epilogue_quad = both halves back to back: a round trip per operand).
+template <typename Tag> struct EpiOps { float4 bias, rv; typename Elem<Tag>::quad_t res, bl; };
 template <typename Tag>
-__device__ __forceinline__ void epilogue_quad(const GemmP& p, int gm, int gn, float (&v)[4]) {
+__device__ __forceinline__ EpiOps<Tag> epi_load(const GemmP& p, int gm, int gn) {
   typedef typename Elem<Tag>::quad_t quad_t;
   constexpr int ES = Elem<Tag>::ES;
-  if (p.bias) {
-    const float4 b = *(const float4*)(p.bias + gn);
-    v[0] += b.x; v[1] += b.y; v[2] += b.z; v[3] += b.w;
-  }
-#pragma unroll
-  for (int e = 0; e < 4; ++e) v[e] *= p.acc_scale;
+  EpiOps<Tag> o;
+  o.bias = o.rv = make_float4(0.f, 0.f, 0.f, 0.f);
+  o.res = o.bl = zero_quad<Tag>();
+  if (p.bias) o.bias = *(const float4*)(p.bias + gn);
   if (p.rowvec) {
     int rg = gm / p.rowvec_rows;
     if (p.rowvec_mod > 0) rg %= p.rowvec_mod;
-    const float4 b = *(const float4*)(p.rowvec + (long)rg * p.ld_rowvec + gn);
-    v[0] += b.x; v[1] += b.y; v[2] += b.z; v[3] += b.w;
+    o.rv = *(const float4*)(p.rowvec + (long)rg * p.ld_rowvec + gn);
   }
+  if (p.residual) o.res = *(const quad_t*)(p.residual + ((long)gm * p.ld_res + gn) * ES);
+  if (p.blend) o.bl = *(const quad_t*)(p.blend + ((long)gm * p.ld_blend + gn) * ES);
+  return o;
+}
+template <typename Tag>
+__device__ __forceinline__ void epi_finish(const GemmP& p, const EpiOps<Tag>& o, int gm, int gn, float (&v)[4]) {
+  typedef typename Elem<Tag>::quad_t quad_t;
+  constexpr int ES = Elem<Tag>::ES;
+  if (p.bias) { v[0] += o.bias.x; v[1] += o.bias.y; v[2] += o.bias.z; v[3] += o.bias.w; }
+#pragma unroll
+  for (int e = 0; e < 4; ++e) v[e] *= p.acc_scale;
+  if (p.rowvec) { v[0] += o.rv.x; v[1] += o.rv.y; v[2] += o.rv.z; v[3] += o.rv.w; }
   if (p.residual) {
     float r4[4];
-    quad_to_f32<Tag>(*(const quad_t*)(p.residual + ((long)gm * p.ld_res + gn) * ES), r4);
+    quad_to_f32<Tag>(o.res, r4);
 #pragma unroll
     for (int e = 0; e < 4; ++e) v[e] += r4[e];
   }
   if (p.blend) {
     float r4[4];
-    quad_to_f32<Tag>(*(const quad_t*)(p.blend + ((long)gm * p.ld_blend + gn) * ES), r4);
+    quad_to_f32<Tag>(o.bl, r4);
 #pragma unroll
     for (int e = 0; e < 4; ++e) v[e] = p.alpha * r4[e] + (1.0f - p.alpha) * v[e];
   }
@@ -234,6 +248,12 @@ __device__ __forceinline__ void epilogue_quad(const GemmP& p, int gm, int gn, fl
   } else {
     *(quad_t*)(p.out + ((long)gm * p.ldo + gn) * ES) = f32_to_quad<Tag>(v);
   }
+}
+
+template <typename Tag>
+__device__ __forceinline__ void epilogue_quad(const GemmP& p, int gm, int gn, float (&v)[4]) {
+  const EpiOps<Tag> o = epi_load<Tag>(p, gm, gn);
+  epi_finish<Tag>(p, o, gm, gn, v);
 }
 
 template <int N> __device__ __forceinline__ void wait_vmcnt() {
@@ -1106,13 +1126,14 @@ __global__ __launch_bounds__(256) void splitk_epilogue_kernel(const GemmP p) {
   const int nq = p.n >> 2;
   for (long q = (long)blockIdx.x * blockDim.x + threadIdx.x; q < quads; q += (long)gridDim.x * blockDim.x) {
     const int gm = (int)(q / nq), gn = (int)(q - (long)gm * nq) * 4;
+    const EpiOps<Tag> o = epi_load<Tag>(p, gm, gn);           // (requested with the slabs: one round trip)
     float4 a = *(const float4*)(p.ws + (long)gm * p.n + gn);
     for (int s2 = 1; s2 < p.splitk; ++s2) {
       const float4 b = *(const float4*)(p.ws + ((long)s2 * p.m + gm) * p.n + gn);
       a.x += b.x; a.y += b.y; a.z += b.z; a.w += b.w;
     }
     float v[4] = {a.x, a.y, a.z, a.w};
-    epilogue_quad<Tag>(p, gm, gn, v);
+    epi_finish<Tag>(p, o, gm, gn, v);
   }
 }
 
@@ -1130,13 +1151,14 @@ __global__ __launch_bounds__(256) void splitk_epilogue_stats_kernel(const GemmP 
   if (gn < p.n) {
     for (int r = rl; r < R; r += 32) {
       const int gm = rt * R + r;                              // < m: m is a multiple of R (tt_gemm_stats_rows)
+      const EpiOps<Tag> o = epi_load<Tag>(p, gm, gn);
       float4 a = *(const float4*)(p.ws + (long)gm * p.n + gn);
       for (int s2 = 1; s2 < p.splitk; ++s2) {
         const float4 b = *(const float4*)(p.ws + ((long)s2 * p.m + gm) * p.n + gn);
         a.x += b.x; a.y += b.y; a.z += b.z; a.w += b.w;
       }
       float v[4] = {a.x, a.y, a.z, a.w};
-      epilogue_quad<Tag>(p, gm, gn, v);
+      epi_finish<Tag>(p, o, gm, gn, v);
 #pragma unroll
       for (int e = 0; e < 4; ++e) { const float x = round_store<Tag>(v[e]); cs[e] += x; cq[e] = fmaf(x, x, cq[e]); }
     }
@@ -1154,9 +1176,106 @@ __global__ __launch_bounds__(256) void splitk_epilogue_stats_kernel(const GemmP 
     }
   }
 }
+// ... and with the GroupNorm that reads the output (GemmP.gn_out; the coarsest UNet levels, where everything is bound by launches):
+// block (segment of p.stat_rows rows = one image or the frames of a video, one of the 32 groups), thread (column quad of the group, row lane)
+// finishes MAXR rows -- slabs summed in order, epilogue, `out` stored --, keeps the STORED values in registers, the block adds them up
+// (fp64, fixed order: lanes by shuffle, waves through LDS), and every thread normalises what it holds.  One launch instead of the reduction
+// and a GroupNorm launch; the normalised tensor is computed from the same rounded values and the same formula as tt_groupnorm_tiles.
+// Row r of the segment belongs to lane r % rl_n, slot r / rl_n; the slab loads of all MAXR slots are issued before the first is used
+// (slots beyond the segment re-read its last row and count for nothing: no branches around the loads).
+template <typename Tag, int MAXR>
+__global__ __launch_bounds__(1024) void splitk_epilogue_gn_kernel(const GemmP p, const int rl_n) {
+  typedef typename Elem<Tag>::quad_t quad_t;
+  constexpr int ES = Elem<Tag>::ES;
+  __shared__ double wsum[16][2];
+  __shared__ float s_stat[2];
+  kernarg_touch<sizeof(GemmP)>();
+  const int R = p.stat_rows, sg = blockIdx.x, grp = blockIdx.y, tid = threadIdx.x;
+  const int cpg = p.n >> 5, nq = cpg >> 2;
+  const int rl = tid / nq, qd = tid - rl * nq;
+  const int gn = grp * cpg + qd * 4;
+  const bool lane_ok = rl < rl_n;
+  float x[MAXR][4];
+  int gmr[MAXR];
+  bool ok[MAXR];
+  EpiOps<Tag> eo[MAXR];
+  const float4 g4 = *(const float4*)(p.gn_gamma + gn), b4 = *(const float4*)(p.gn_beta + gn);
+#pragma unroll
+  for (int i = 0; i < MAXR; ++i) {
+    const int r = rl + i * rl_n;
+    ok[i] = lane_ok && r < R;
+    gmr[i] = sg * R + (ok[i] ? r : R - 1);                    // < m: m is a multiple of R (tt_gemm_gn_fused)
+    eo[i] = epi_load<Tag>(p, gmr[i], gn);
+    const float4 a = *(const float4*)(p.ws + (long)gmr[i] * p.n + gn);
+    x[i][0] = a.x; x[i][1] = a.y; x[i][2] = a.z; x[i][3] = a.w;
+  }
+  for (int s2 = 1; s2 < p.splitk; ++s2) {
+#pragma unroll
+    for (int i = 0; i < MAXR; ++i) {
+      const float4 b = *(const float4*)(p.ws + ((long)s2 * p.m + gmr[i]) * p.n + gn);
+      x[i][0] += b.x; x[i][1] += b.y; x[i][2] += b.z; x[i][3] += b.w;
+    }
+  }
+  double cs = 0.0, cq = 0.0;
+#pragma unroll
+  for (int i = 0; i < MAXR; ++i) {
+    if (ok[i]) {                                              // (the epilogue stores `out`)
+      epi_finish<Tag>(p, eo[i], gmr[i], gn, x[i]);
+#pragma unroll
+      for (int e = 0; e < 4; ++e) { x[i][e] = round_store<Tag>(x[i][e]); cs += (double)x[i][e]; cq += (double)x[i][e] * (double)x[i][e]; }
+    }
+  }
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) { cs += __shfl_xor(cs, o); cq += __shfl_xor(cq, o); }
+  if ((tid & 63) == 0) { wsum[tid >> 6][0] = cs; wsum[tid >> 6][1] = cq; }
+  __syncthreads();
+  if (tid == 0) {
+    double a = 0.0, b = 0.0;
+    for (int w = 0; w < (((int)blockDim.x + 63) >> 6); ++w) { a += wsum[w][0]; b += wsum[w][1]; }
+    const double cnt = (double)R * cpg, mean = a / cnt;
+    double var = b / cnt - mean * mean;
+    if (var < 0.0) var = 0.0;
+    s_stat[0] = (float)mean;
+    s_stat[1] = (float)(1.0 / sqrt(var + (double)p.gn_eps));
+  }
+  __syncthreads();
+  const float mean = s_stat[0], rstd = s_stat[1];
+  const float sc[4] = {rstd * g4.x, rstd * g4.y, rstd * g4.z, rstd * g4.w};
+  const float sh[4] = {b4.x - mean * sc[0], b4.y - mean * sc[1], b4.z - mean * sc[2], b4.w - mean * sc[3]};
+#pragma unroll
+  for (int i = 0; i < MAXR; ++i) {
+    if (ok[i]) {
+      float y[4];
+#pragma unroll
+      for (int e = 0; e < 4; ++e) { const float t = fmaf(x[i][e], sc[e], sh[e]); y[e] = p.gn_silu ? silu_f(t) : t; }
+      *(quad_t*)(p.gn_out + ((long)gmr[i] * p.ld_gn + gn) * ES) = f32_to_quad<Tag>(y);
+    }
+  }
+}
+// rows a thread of splitk_epilogue_gn_kernel holds for segments of `seg` rows: the smallest of 1, 2, 4, 8 with which (row lanes x column
+// quads of a group) fit 1024 threads (0: the segment does not fit one block); *rl_n = row lanes
+static inline int splitk_gn_rows(int seg, int n, int* rl_n) {
+  const int nq = n / 128;                                   // column quads of one group (n / 32 channels)
+  if (nq <= 0 || nq > 256 || seg <= 0) return 0;
+  for (int mr = 1; mr <= 8; mr *= 2) {
+    const int lanes = (seg + mr - 1) / mr;
+    if ((long)lanes * nq <= 1024) { if (rl_n) *rl_n = lanes; return mr; }
+  }
+  return 0;
+}
 // second pass of a split-K launch (with or without the statistics)
 template <typename Tag>
 static inline void launch_splitk_epilogue(const GemmP& p, hipStream_t st) {
+  if (p.gn_out) {
+    int rl_n = 0;
+    const int mr = splitk_gn_rows(p.stat_rows, p.n, &rl_n);
+    const dim3 grid(p.m / p.stat_rows, 32), block((rl_n * (p.n / 128) + 63) / 64 * 64);
+    if (mr == 1) hipLaunchKernelGGL((splitk_epilogue_gn_kernel<Tag, 1>), grid, block, 0, st, p, rl_n);
+    else if (mr == 2) hipLaunchKernelGGL((splitk_epilogue_gn_kernel<Tag, 2>), grid, block, 0, st, p, rl_n);
+    else if (mr == 4) hipLaunchKernelGGL((splitk_epilogue_gn_kernel<Tag, 4>), grid, block, 0, st, p, rl_n);
+    else hipLaunchKernelGGL((splitk_epilogue_gn_kernel<Tag, 8>), grid, block, 0, st, p, rl_n);
+    return;
+  }
   if (p.stats) {
     hipLaunchKernelGGL(splitk_epilogue_stats_kernel<Tag>, dim3(p.m / p.stat_rows, (p.n + 31) / 32), dim3(256), 0, st, p);
     return;

@@ -87,12 +87,15 @@ def gemm(a0: torch.Tensor, w: torch.Tensor, *, a1: Optional[torch.Tensor] = None
          bias=None, acc_scale: float = 1.0, rowvec=None, rowvec_rows: int = 0, rowvec_mod: int = 0, geglu: bool = False, residual=None,
          blend=None, alpha: float = 0.0, out: Optional[torch.Tensor] = None, out_f32: bool = False, m: Optional[int] = None,
          out_col_pad: Optional[Tuple[int, int]] = None, ln_fold: int = 0, ln_eps: float = 1e-5,
-         out_fp8: bool = False, stats: int = 0) -> torch.Tensor:
+         out_fp8: bool = False, stats: int = 0, gn=None) -> torch.Tensor:
     """out[m, n] = epilogue(gather(a0|a1) @ w.T); see TtGemmArgs in include/ttvdm.h.
     stats = S > 0: the output will be read by a GroupNorm whose segments are S rows (h*w for per-image statistics, frames*h*w for the
     temporal ResBlock) -- ask the launch for its per-tile column sums (TtGemmArgs.stats_out).  When the route has a statistics
     epilogue AND S is a whole number of its tiles they are attached to the returned tensor (``out._tt_stats = (buffer, rows per
     tile)``) and groupnorm() normalises in one pass from them; otherwise the launch runs without them (no cost).
+    gn = (gamma, beta, eps, silu) next to stats = S: the parameters of THAT GroupNorm.  Where the launch ends in a split-K reduction pass
+    (the two coarsest UNet levels) the pass also normalises (TtGemmArgs.gn_out): the result is attached (``out._tt_gn``) and groupnorm()
+    with the same parameters returns it without a launch; elsewhere `gn` is ignored and the statistics route above applies.
     conv = (nimg, hin, win, hout, wout, stride, upsample); tconv = (frames, hw).
     ln_fold: 1 = rows of a0 / 2 = rows of w are LayerNorm inputs (weights pre-folded by packing.fold_layernorm).
     out_fp8: the output is stored as OCP e4m3 (torch.float8_e4m3fn), the operand format of attention(..., fp8 path)."""
@@ -143,10 +146,17 @@ def gemm(a0: torch.Tensor, w: torch.Tensor, *, a1: Optional[torch.Tensor] = None
         g.ws, g.ws_bytes = ws.data_ptr(), ws.numel()
     if hasattr(out, "_tt_stats"):
         del out._tt_stats                                   # `out` is being overwritten: sums attached by an earlier launch are stale
-    sbuf = None
+    if hasattr(out, "_tt_gn"):
+        del out._tt_gn
+    sbuf = gnbuf = None
+    if stats and gn is not None and GN_FUSED:
+        g.stats_seg = int(stats)
+        if lib.tt_gemm_gn_fused(C.byref(g)):
+            gnbuf = torch.empty((g.m, n), dtype=out.dtype, device=a0.device)
+            g.gn_out, g.ld_gn, g.gn_gamma, g.gn_beta, g.gn_eps, g.gn_silu = gnbuf.data_ptr(), n, _p(gn[0]), _p(gn[1]), float(gn[2]), int(bool(gn[3]))
     # (only for outputs up to the finest level's size at 256x448: the statistics epilogue costs 1-2.6 us PER TILE of a workgroup, so a
     # launch that walks 3-4 tiles per CU -- 512x896 latents -- pays more than the consumer's saved pass: 107.5 -> 108.5 ms/step, one call)
-    if stats and GN_TILES and g.m * n <= GN_TILES_MAX_ELEMS:
+    if stats and gnbuf is None and GN_TILES and g.m * n <= GN_TILES_MAX_ELEMS:
         g.stats_seg = int(stats) if GN_TILES_SEG else 0        # (lets the split-K routes and the tiled template pick a tile height that divides the segment)
         srows = lib.tt_gemm_stats_rows(C.byref(g))
         if srows > 0 and lib.tt_groupnorm_tiles_supported(int(stats), n, srows, g.dtype):
@@ -156,6 +166,8 @@ def gemm(a0: torch.Tensor, w: torch.Tensor, *, a1: Optional[torch.Tensor] = None
     check(lib.tt_gemm(C.byref(g), _stream()), "tt_gemm")
     if sbuf is not None:
         out._tt_stats = (sbuf, srows)
+    if gnbuf is not None:
+        out._tt_gn = (gnbuf, gn[0].data_ptr(), gn[1].data_ptr(), float(gn[2]), bool(gn[3]), int(stats))
     if ev is not None:
         cfg = (C.c_int32 * 7)()
         lib.tt_gemm_plan(C.byref(g), cfg)
@@ -306,6 +318,7 @@ GN_CROSS_MAX_ROWS = int(os.environ.get("TT_GN_CROSS_ROWS", "0"))
 # GroupNorm on the statistics-pass kernels (A/B)
 GN_TILES = os.environ.get("TT_GN_TILES", "1") != "0"
 GN_TILES_SEG = os.environ.get("TT_GN_TILES_SEG", "1") != "0"       # ... also on the split-K routes (coarse levels) and with per-wave-row sums of the tiled template (A/B)
+GN_FUSED = os.environ.get("TT_GN_FUSED", "1") != "0"        # GroupNorm inside the split-K reduction pass (TtGemmArgs.gn_out), A/B
 GN_TILES_MAX_ELEMS = int(os.environ.get("TT_GN_TILES_MAX_ELEMS", str(17 << 20)))
 _GN_EMULATE = os.environ.get("TT_GN_EMULATE", "0") == "1"
 _GN_EMU_CACHE = {}
@@ -323,6 +336,9 @@ def groupnorm(x0, x1, nimg, hw, frames_per_group, gamma, beta, eps, silu: bool):
         if ss is None:
             ss = _GN_EMU_CACHE[key] = (torch.ones((nimg, c0 + c1), dtype=torch.float32, device=x0.device), torch.zeros((nimg, c0 + c1), dtype=torch.float32, device=x0.device))
         return groupnorm_apply(x0, x1, nimg, hw, ss[0], ss[1], silu)
+    fz = getattr(x0, "_tt_gn", None) if x1 is None else None
+    if fz is not None and fz[1:] == (gamma.data_ptr(), beta.data_ptr(), float(eps), bool(silu), frames_per_group * hw):
+        return fz[0]                                         # the producer's reduction pass already normalised (gemm(..., gn=))
     st = getattr(x0, "_tt_stats", None) if (GN_TILES and x1 is None) else None
     if st is not None and nimg % frames_per_group == 0 and x0.is_contiguous() and st[0].shape[2] == c0 and \
             lib.tt_groupnorm_tiles_supported(frames_per_group * hw, c0, st[1], _code(x0.dtype)):
@@ -365,6 +381,8 @@ def add_rowvec(x, rowvec, rows_per_vec: int, nvec: int, out=None):
     y = torch.empty((rows, c), dtype=x.dtype, device=x.device) if out is None else out
     if hasattr(y, "_tt_stats"):
         del y._tt_stats
+    if hasattr(y, "_tt_gn"):
+        del y._tt_gn
     assert y.shape == x.shape and y.stride(1) == 1 and y.dtype == x.dtype
     check(lib.tt_add_rowvec(_p(x), x.stride(0), rows, c, _p(rowvec), rowvec.stride(0), rows_per_vec, nvec, _p(y), y.stride(0),
                             _code(x.dtype), _stream()), "tt_add_rowvec")

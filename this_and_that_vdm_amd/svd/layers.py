@@ -275,7 +275,8 @@ class ResnetBlock2D(_Packable):
             self.ws, self.bs = pack_conv1x1(self.conv_shortcut.weight.detach().to(dtype)), _f32(self.conv_shortcut.bias)
         self.film = reg.add_film(self.time_emb_proj) if self.time_emb_proj is not None else None
 
-    def forward(self, x0, x1, g: Geom, ctx: StepContext):
+    def forward(self, x0, x1, g: Geom, ctx: StepContext, next_gn=None):
+        """next_gn = (gamma, beta, eps, silu) of the cross-frame GroupNorm that reads this block's output (TemporalResnetBlock.norm1)"""
         film = None
         if self.film is not None:
             off, c = self.film
@@ -295,7 +296,8 @@ class ResnetBlock2D(_Packable):
         else:
             a = ops.groupnorm(x0, x1, g.n, g.hw, 1, self.g1, self.be1, self.eps, True)
             hmid = ops.gemm(a, self.w1, mode=1, conv=conv, bias=self.b1, rowvec=film, rowvec_rows=g.frames * g.hw if film is not None else 0,
-                            stats=g.hw)                      # norm2 (per image) reads it: per-tile column sums from the epilogue (ops.groupnorm)
+                            stats=g.hw, gn=(self.g2, self.be2, self.eps, True))      # norm2 (per image) reads it: per-tile column sums from the
+                                                                                         # epilogue, or normalised by the split-K reduction pass
         if self.conv_shortcut is not None:
             xs = ops.gemm(x0, self.ws, a1=x1, bias=self.bs)
         else:
@@ -307,7 +309,7 @@ class ResnetBlock2D(_Packable):
             return ops.conv3x3(hmid, None, self.w2, g.n, g.h, g.w, gn=st2, silu=True, bias=self.b2, residual=xs)
         a = ops.groupnorm(hmid, None, g.n, g.hw, 1, self.g2, self.be2, self.eps, True)
         # (read by the temporal block's norm1: statistics over the frames x h x w rows of a video)
-        return ops.gemm(a, self.w2, mode=1, conv=conv, bias=self.b2, residual=xs, stats=g.frames * g.hw)
+        return ops.gemm(a, self.w2, mode=1, conv=conv, bias=self.b2, residual=xs, stats=g.frames * g.hw, gn=next_gn)
 
 
 class TemporalResnetBlock(_Packable):
@@ -337,7 +339,7 @@ class TemporalResnetBlock(_Packable):
         film = g.film(ctx.film, *self.film) if self.film is not None else None
         a = _gn(s, None, g, g.frames, self.g1, self.be1, self.eps, True)
         t = ops.gemm(a, self.w1, mode=2, tconv=(g.frames, g.hw), bias=self.b1, rowvec=film,
-                     rowvec_rows=g.frames * g.hw if film is not None else 0, stats=g.frames * g.hw)
+                     rowvec_rows=g.frames * g.hw if film is not None else 0, stats=g.frames * g.hw, gn=(self.g2, self.be2, self.eps, True))
         a = _gn(t, None, g, g.frames, self.g2, self.be2, self.eps, True)
         # x_temporal = s + conv2(...);  out = alpha*s + (1-alpha)*x_temporal
         # (the block's output: the transformer's GroupNorm or the next ResBlock's norm1 reads it)
@@ -379,8 +381,9 @@ class SpatioTemporalResBlock(_Packable):
         self.alpha = self.time_mixer.alpha_value()
 
     def forward(self, x0, x1, g: Geom, ctx: StepContext):
-        s = self.spatial_res_block(x0, x1, g, ctx)
-        return self.temporal_res_block(s, g, ctx, self.alpha)
+        t = self.temporal_res_block
+        s = self.spatial_res_block(x0, x1, g, ctx, next_gn=(t.g1, t.be1, t.eps, True))
+        return t(s, g, ctx, self.alpha)
 
 
 class Downsample2D(_Packable):
