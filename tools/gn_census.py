@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """Which route every GroupNorm of one denoise step takes (GPU box): from the producer's tile sums (one pass, one launch), two sources
-(the up blocks' skip concat: statistics-pass kernels), or no sums attached (the producer's route / tile height does not serve the
+(the up blocks' skip concat: statistics-pass kernels), normalised by the producer's split-K reduction pass (no launch), or no sums attached (the producer's route / tile height does not serve the
 segment).          python tools/gn_census.py [vgl|vl] [lo|ref|hi]"""
 import os, sys
 from collections import Counter
@@ -22,7 +22,8 @@ def main():
 
     def spy(x0, x1, nimg, hw, fpg, *a, **k):
         st = getattr(x0, "_tt_stats", None)
-        how = "two sources" if x1 is not None else (f"tiles of {st[1]} rows" if st is not None and (fpg * hw) % st[1] == 0 else "no sums attached")
+        fz = getattr(x0, "_tt_gn", None) if x1 is None else None
+        how = "by the producer's split-K reduction pass" if fz is not None and fz[5] == fpg * hw else "two sources" if x1 is not None else (f"tiles of {st[1]} rows" if st is not None and (fpg * hw) % st[1] == 0 else "no sums attached")
         seen[(hw, x0.shape[-1] + (0 if x1 is None else x1.shape[-1]), "cross-frame" if fpg > 1 else "per image", how)] += 1
         return real(x0, x1, nimg, hw, fpg, *a, **k)
     ops.groupnorm = spy
@@ -32,7 +33,8 @@ def main():
     loop.step(); torch.cuda.synchronize()
     for (hw, c, kind, how), n in sorted(seen.items()):
         print(f"{n:5d} x GroupNorm hw {hw:5d} C {c:5d} {kind:11s} -> {how}")
-    print(f"{sum(seen.values())} GroupNorms, {sum(n for k, n in seen.items() if k[3].startswith('tiles'))} from tile sums")
+    print(f"{sum(seen.values())} GroupNorms, {sum(n for k, n in seen.items() if k[3].startswith('tiles'))} from tile sums, "
+          f"{sum(n for k, n in seen.items() if k[3].startswith('by the'))} inside the producer's reduction pass")
 
 
 if __name__ == "__main__":

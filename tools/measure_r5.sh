@@ -1,5 +1,6 @@
 #!/bin/bash
 # One GPU-box pass that produces the round-5 measurement set under gpurun_out/profiles/ (copied into profiles/ afterwards).
+# profiles/r5_hbm_traffic.json must already belong to the current kernel sources (tools/profile_round.sh; bench.py checks the stamp).
 cd "$GRAFT_REPO_ROOT"; mkdir -p gpurun_out/profiles; P=gpurun_out/profiles
 b() { python bench.py "$@" 2>/dev/null | tail -1; }
 b > $P/r5_bench_lo.json
@@ -10,6 +11,6 @@ b --res hi --no-cpu-baseline --steps 10 --warmup 3 > $P/r5_bench_hi_bf16.json
 b --res hi --attn fp8 --no-cpu-baseline --steps 10 --warmup 3 > $P/r5_bench_hi_fp8.json
 b --block l0hi --steps 20 --warmup 3 > $P/r5_block_l0hi_bf16.json
 b --block l0hi --attn fp8 --steps 20 --warmup 3 > $P/r5_block_l0hi_fp8.json
-for f in lo vl lo_fp16 ref hi_bf16 hi_fp8; do python -c "import json,sys; d=json.load(open('$P/r5_bench_$f.json')); print('$f', round(d['ms_per_step'],3), 'ms', round(d['config']['step_mfma_frac_of_peak'],4), d['roofline']['kernel'] if d['roofline'] else '', round(d['roofline']['frac'],4) if d['roofline'] else '')"; done
+for f in lo vl lo_fp16 ref hi_bf16 hi_fp8; do python -c "import json,sys; d=json.load(open('$P/r5_bench_$f.json')); print('$f', round(d['ms_per_step'],3), 'ms', round(d['config']['step_mfma_frac_of_peak'],4), d['roofline']['kernel'] if d['roofline'] else '', round(d['roofline']['frac'],4) if d['roofline'] else '', d['roofline'].get('traffic') if d['roofline'] else '')"; done
 for f in bf16 fp8; do python -c "import json; d=json.load(open('$P/r5_block_l0hi_$f.json')); print('block $f', round(d['ms_per_step'],3), 'ms frac', round(d['roofline']['frac'],4))"; done
-bash tools/profile_round.sh r5_vgl_lo_bf16 lo 2>&1 | tail -30
+python tools/gn_census.py 2>/dev/null > $P/r5_gn_census.txt; tail -1 $P/r5_gn_census.txt
