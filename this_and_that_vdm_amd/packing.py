@@ -71,12 +71,15 @@ def zero_sum_round(w: torch.Tensor, dtype: torch.dtype) -> torch.Tensor:
             if not bool((r != 0).any()):
                 break
             u = 2.0 ** (lvl - mant)
+            want = torch.round(r / u).abs()                   # [N]: moves of one ulp of this binade that still fit into the residual
+            if not bool((want != 0).any()):                   # (the binades coarser than every residual: no O(N K) work)
+                continue
             mask = nz & (e == lvl) & ~moved
             if only_other_neighbour:
                 mask = mask & torch.where((r > 0)[:, None], up, dn)
             cnt = mask.sum(dim=1)
-            n = torch.minimum(torch.round(r / u).abs(), cnt.double()) * torch.sign(r)
-            sel = mask & (torch.cumsum(mask, dim=1) <= n.abs()[:, None])
+            n = torch.minimum(want, cnt.double()) * torch.sign(r)
+            sel = mask & (torch.cumsum(mask, dim=1, dtype=torch.int32) <= n.abs()[:, None])
             q = q - sel.double() * (torch.sign(n) * u)[:, None]
             moved = moved | sel
             r = r - n * u
