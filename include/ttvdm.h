@@ -149,8 +149,8 @@ size_t tt_gemm_ws_bytes(const TtGemmArgs* args);
  * process; -1 restores the built-in heuristic.  Also settable by the TT_GEMM_CFG environment variable. */
 int tt_gemm_set_tile_override(int32_t cfg);
 /* tuning knob: route the 320 x 320 linears with m >= 4096 (mode 0, one source, bias / residual / self-blend epilogue) to
- * the persistent W-in-registers streaming kernel.  Off by default (faster alone, slower next to a concurrent branch);
- * also settable by TT_GEMM_SQ320=1. */
+ * the persistent W-in-registers streaming kernel: 0 never, 1 always, 2 (the default) from 131 072 rows on -- 64x112 latents, where the
+ * big-tile kernel walks 3.06 rounds of tiles; at 32x56 it is faster alone and slower inside the step.  Also TT_GEMM_SQ320=0|1|2. */
 int tt_gemm_set_streaming_square(int32_t on);
 /* tuning knob for the N = 320 t big-tile kernels (gemm_w320.hip), for A/B measurements and tests; also TT_GEMM_W320=0|1|2|3|4:
  *   0  keep these problems on the tiled kernels;

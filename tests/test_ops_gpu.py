@@ -791,7 +791,7 @@ def test_gemm_square_320_streaming_kernel(ops, dtype, m, epi):
         assert lib.tt_gemm_set_streaming_square(1) == 0
         _run_square_320(ops, lib, dtype, m, epi, a, w, bias, res)
     finally:
-        lib.tt_gemm_set_streaming_square(0)
+        lib.tt_gemm_set_streaming_square(2)                  # back to the default: by size
 
 
 def _run_square_320(ops, lib, dtype, m, epi, a, w, bias, res):

@@ -154,12 +154,15 @@ extern "C" int tt_gemm_set_tile_override(int32_t cfg) {
 
 static int g_sq320 = -1;
 extern "C" int tt_gemm_set_streaming_square(int32_t on) {
-  g_sq320 = on ? 1 : 0;
+  g_sq320 = on == 2 ? 2 : (on ? 1 : 0);          // 2: by size (the default)
   return TT_OK;
 }
 
 bool sq320_ok(const TtGemmArgs* a) {
-  if (g_sq320 < 0) { const char* e = getenv("TT_GEMM_SQ320"); g_sq320 = e ? atoi(e) : 0; }
+  // 0 off, 1 on, 2 (default) by size: at 64x112 latents (200 704 rows: 784 big tiles = 3.06 rounds of 196) the 32-row streaming kernel wins
+  // (block l0hi 5.46 -> 5.39 ms, fp8 4.995 -> 4.91; 512x896 step 109.6 -> 109.1 ms), at 32x56 it loses (29.04 -> 29.32 ms): one call each, interleaved
+  if (g_sq320 < 0) { const char* e = getenv("TT_GEMM_SQ320"); g_sq320 = e ? atoi(e) : 2; }
+  if (g_sq320 == 2 && a->m < 131072) return false;
   return g_sq320 && a->dtype != TT_F32 && !a->ln_fold && !a->out_fp8 && forced_cfg() < 0 && a->mode == 0 && a->k1 == 0 && a->k0 == SQ_K && a->n == SQ_N && a->m >= 4096 &&
          !a->geglu && !a->rowvec && !a->out_f32 && !a->out_col_hw &&
          (!a->blend || (a->blend == a->residual && a->ld_blend == a->ld_res));
