@@ -74,6 +74,8 @@ def test_gemm_dispatch_rules_of_the_persistent_kernel(lib):
         cfg, ws = plan(m, n, k, bf16, ln_fold=1, geglu=1)
         assert cfg[:4] == pp and ws == 0, (m, n, k, cfg)
     assert plan(3072, 10240, 1280, bf16)[0][:4] == pp                      # 480 tiles: 1.9 rounds, 94 % full
+    assert plan(10752, 5120, 640, bf16, ln_fold=1, geglu=1)[0][:4] == pp   # 256x384: 840 tiles = 3.3 rounds -> 38 tile rows (2.97 rounds) + 1024 rows on the tiled kernel
+    assert plan(2688, 10240, 1280, bf16, ln_fold=1, geglu=1)[0][:4] != pp  # ... its third level has too few tiles either way
     assert plan(50176, 960, 320, bf16, ln_fold=1)[0][:4] != pp             # 784 tiles: 4 rounds at 77 %
     assert plan(784, 10240, 1280, bf16, ln_fold=1, geglu=1)[0][:4] != pp   # 160 tiles
     assert plan(50176, 2560, 320, f32)[0][:4] != pp                        # fp32 storage
@@ -107,7 +109,8 @@ def test_gemm_dispatch_rules_of_the_big_tile_kernel(lib):
     assert plan(50176, 960, 320, ln_fold=1)[0] == w320                                   # LayerNorm-folded QKV: 588 tiles, 77 %
     assert plan(50176, 320, 320, k1=320, lda1=320, **conv)[0] == w320                    # conv over a skip concat
     assert plan(50176, 320, 320, mode=2, frames=14, hw=1792)[0] == w320
-    assert plan(200704, 320, 320)[0] == w320                                             # 64x112 latents: 784 tiles
+    assert plan(200704, 320, 640)[0] == w320                                             # 64x112 latents: 784 tiles
+    assert plan(200704, 320, 320)[0][:2] == [32, 320]                                    # ... whose 320 x 320 linears take the 32-row streaming kernel (from 131072 rows on)
     assert plan(50176, 320, 320, rowvec=16, rowvec_rows=1792, ld_rowvec=320)[0] == w320
     assert plan(50176, 320, 320, rowvec=16, rowvec_rows=16, ld_rowvec=320)[0] != w320     # row-vector groups shorter than a fragment row
     assert plan(50176, 320, 320, rowvec=16, rowvec_rows=1, rowvec_mod=2, ld_rowvec=320)[0] == w320   # ... except the even / odd form (ABI 7)

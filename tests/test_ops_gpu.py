@@ -480,7 +480,8 @@ def test_layernorm_and_fused_frame_embedding(ops, dtype, c):
 @pytest.mark.parametrize("ln,geglu,m,n,k", [(1, 1, 8192 - 37, 6144 - 16, 128), (1, 0, 8192, 6144 - 48, 192), (0, 1, 8192, 6144, 128),
                                             (0, 0, 8192 - 200, 6144, 320),
                                             (1, 1, 3136, 10240, 1280),      # 12 whole tile rows + a ragged row of 64: ragged tiles last, to the idle CUs
-                                            (0, 0, 3072 + 130, 10240, 256)])  # 130 ragged rows: launched in two parts (12 whole tile rows + 130 rows on the tiled kernel)
+                                            (0, 0, 3072 + 130, 10240, 256),   # 130 ragged rows: launched in two parts (12 whole tile rows + 130 rows on the tiled kernel)
+                                            (1, 1, 10752, 5120, 640)])        # 256x384: 42 tile rows = 3.3 rounds -> 38 tile rows on the persistent kernel + 1024 rows on the tiled one
 def test_gemm_persistent_pingpong_kernel(ops, dtype, ln, geglu, m, n, k):
     """gemm_pp.hip: tall-and-wide Linear problems without per-row epilogue operands (>= 460 tiles of 256 x 256: ~1.8 rounds of the 256 CUs) run on
     the persistent ping-pong kernel -- fused LayerNorm statistics, bias, GEGLU or plain 16-bit output, ragged last tile rows and

@@ -260,11 +260,20 @@ int w320_split(const TtGemmArgs* a) {
 bool w320_ok(const TtGemmArgs* a) { return w320_route(a) != 0; }
 static bool ws_fits(const TtGemmArgs* a, int split) { return a->ws && (size_t)a->ws_bytes >= (size_t)split * a->m * a->n * sizeof(float); }
 // rows the persistent kernel takes when the problem is launched in two parts (0: one launch)
+// (also for row counts that ARE whole tile rows but leave the last round of tiles poorly filled: 10752 x 5120 at 256x384 -- 840 tiles = 3.3
+// rounds -- runs its first 38 tile rows, 2.97 rounds, on the persistent kernel and the last 1024 rows on the tiled one; at most 1/8 of the
+// rows go to the tail)
 static int pp_split_rows(const TtGemmArgs* a) {
-  if ((a->m & 255) == 0 || a->m < 512 || pp_ok(a)) return 0;
+  if (a->m < 512 || pp_ok(a)) return 0;
+  static int whole = -1;                                                     // TT_PP_SPLIT_WHOLE=0: ragged row counts only (A/B)
+  if (whole < 0) { const char* e = getenv("TT_PP_SPLIT_WHOLE"); whole = e ? atoi(e) : 1; }
+  if ((a->m & 255) == 0 && (!whole || w320_route(a) || sq320_ok(a))) return 0;       // (whole tile rows: only problems no big-tile kernel of their own serves)
   TtGemmArgs head = *a;
-  head.m = a->m & ~255;
-  return pp_ok(&head) ? head.m : 0;
+  for (int tr = a->m >> 8; tr >= 2 && (long)(a->m - tr * 256) * 8 <= a->m; --tr) {
+    head.m = tr * 256;
+    if (head.m < a->m && pp_ok(&head)) return head.m;
+  }
+  return 0;
 }
 static void pp_split(const TtGemmArgs* a, int rows, TtGemmArgs* head, TtGemmArgs* tail) {
   const size_t es = 2;                                      // 16-bit storage (pp_ok)
