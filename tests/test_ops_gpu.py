@@ -481,7 +481,9 @@ def test_layernorm_and_fused_frame_embedding(ops, dtype, c):
                                             (0, 0, 8192 - 200, 6144, 320),
                                             (1, 1, 3136, 10240, 1280),      # 12 whole tile rows + a ragged row of 64: ragged tiles last, to the idle CUs
                                             (0, 0, 3072 + 130, 10240, 256),   # 130 ragged rows: launched in two parts (12 whole tile rows + 130 rows on the tiled kernel)
-                                            (1, 1, 10752, 5120, 640)])        # 256x384: 42 tile rows = 3.3 rounds -> 38 tile rows on the persistent kernel + 1024 rows on the tiled one
+                                            (1, 1, 10752, 5120, 640),         # 256x384: 840 tiles, 3.3 rounds (82 %): the GEGLU projections' lower bar
+                                            (1, 0, 10752, 4864, 640),         # ... without GEGLU (798 tiles, 78 %): 40 tile rows on the persistent kernel + 512 rows on the tiled one
+                                            (1, 1, 2688, 10240, 1280)])       # ... third level: 10 whole tile rows (400 tiles, 78 %) + 128 rows tiled
 def test_gemm_persistent_pingpong_kernel(ops, dtype, ln, geglu, m, n, k):
     """gemm_pp.hip: tall-and-wide Linear problems without per-row epilogue operands (>= 460 tiles of 256 x 256: ~1.8 rounds of the 256 CUs) run on
     the persistent ping-pong kernel -- fused LayerNorm statistics, bias, GEGLU or plain 16-bit output, ragged last tile rows and

@@ -184,6 +184,14 @@ bool pp_ok(const TtGemmArgs* a) {
     return false;
   const long tiles = (long)ceil_div(a->m, 256) * ceil_div(a->n, 256);
   const long rounds = (tiles + 255) / 256;
+  // The GEGLU projections have their own, lower bar (TT_PP_GEGLU_MIN_TILES / _MIN_FILL, A/B): their alternative is the tiled template at
+  // 640-670 TFLOP/s, which a persistent launch beats even with a 75 %-full last round -- 256x384: 10752 x 5120 (840 tiles, 82 %) and
+  // 2688 x 10240 (400 whole tiles, 78 %): --res ref 27.72 -> 27.06 ms with 400 / 75 against 460 / 90 (one call, interleaved).  256x448 and
+  // 512x896 do not change: their projections pass either bar or fall below both.
+  static int g_min_tiles = -1, g_min_fill = -1;
+  if (g_min_tiles < 0) { const char* e = getenv("TT_PP_GEGLU_MIN_TILES"); g_min_tiles = e ? atoi(e) : 400; }
+  if (g_min_fill < 0) { const char* e = getenv("TT_PP_GEGLU_MIN_FILL"); g_min_fill = e ? atoi(e) : 75; }
+  if (a->geglu) return tiles >= g_min_tiles && tiles * 100 >= rounds * 256 * g_min_fill;
   return tiles >= 460 && tiles * 10 >= rounds * 256 * 9;      // ~2 rounds of tiles per CU or more, last round >= 90 % full on average
 }
 // The 256 x 320 big-tile kernel (gemm_w320.hip) takes 16-bit problems whose output width is a multiple of 320 and whose row count
