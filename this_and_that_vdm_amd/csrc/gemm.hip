@@ -192,7 +192,10 @@ bool pp_ok(const TtGemmArgs* a) {
   if (g_min_tiles < 0) { const char* e = getenv("TT_PP_GEGLU_MIN_TILES"); g_min_tiles = e ? atoi(e) : 400; }
   if (g_min_fill < 0) { const char* e = getenv("TT_PP_GEGLU_MIN_FILL"); g_min_fill = e ? atoi(e) : 75; }
   if (a->geglu) return tiles >= g_min_tiles && tiles * 100 >= rounds * 256 * g_min_fill;
-  return tiles >= 460 && tiles * 10 >= rounds * 256 * 9;      // ~2 rounds of tiles per CU or more, last round >= 90 % full on average
+  static int p_min_tiles = -1, p_min_fill = -1;              // (TT_PP_MIN_TILES / TT_PP_MIN_FILL, A/B)
+  if (p_min_tiles < 0) { const char* e = getenv("TT_PP_MIN_TILES"); p_min_tiles = e ? atoi(e) : 460; }
+  if (p_min_fill < 0) { const char* e = getenv("TT_PP_MIN_FILL"); p_min_fill = e ? atoi(e) : 90; }
+  return tiles >= p_min_tiles && tiles * 100 >= rounds * 256 * p_min_fill;      // ~2 rounds of tiles per CU or more, last round >= 90 % full on average
 }
 // The 256 x 320 big-tile kernel (gemm_w320.hip) takes 16-bit problems whose output width is a multiple of 320 and whose row count
 // fills most of a round of 256 CUs with 256-row tiles (the finest UNet level: 50176 rows = 196 tiles): Linear (one or two sources,
