@@ -23,6 +23,7 @@ from ..packing import fold_layernorm, pack_conv1x1, pack_conv3x3, pack_geglu, pa
 
 
 ZERO_CTX_TEMPORAL = os.environ.get("TT_ZERO_CTX_T", "1") != "0"      # A/B switch of the temporal zero-context shortcut
+MERGE_FRAMES = os.environ.get("TT_XATTN_MERGE_FRAMES", "1") != "0"    # spatial cross-attention: the frames of a batch element as one sequence (A/B)
 
 
 @dataclass
@@ -518,6 +519,11 @@ def _cross_attention(x, attn: Attention, qp: _QProj, eps, kv, g: Geom, ctx: Step
     out = torch.empty((g.m, c), dtype=x.dtype, device=x.device)
     kw = dict(nseq=g.n, lq=g.hw, heads=attn.heads, head_dim=attn.dim_head, mask=mask, lk=ctx.s_ctx, k_seq_stride=ctx.s_pad,
               v_seq_stride=ctx.s_pad, frames=g.frames, ctx_batches=g.ctx_batches, batch0=g.batch0)
+    if not temporal and MERGE_FRAMES and g.n % g.frames == 0:
+        # the frames of a batch element share its context and are contiguous rows: ONE sequence of frames * hw queries per batch element.
+        # Same result row by row (a query's work does not depend on its block); the 128-query blocks are then full -- at the coarsest
+        # level an image has 28 tokens, i.e. 78 % of every block's query projection and attention was padding (560 -> 80 blocks)
+        kw.update(nseq=g.n // g.frames, lq=g.frames * g.hw, frames=1)
     fused = qp.fused()
     if fused is not None and ops.attention_qproj_supported(x, attn.dim_head, mask):
         return ops.attention(None, ctx.k_all[:, off:off + c], ctx.vt_all[off:off + c], out, qx=x, wq=fused[0], bq=fused[1], ln_eps=eps, **kw)
@@ -682,6 +688,8 @@ class TemporalBasicTransformerBlock(_Packable):
                     # every sequence of this class uses context `cls`: mask 1 with one "batch" spanning all sequences
                     akw = dict(nseq=g.n, lq=g.hw // cb, heads=self.attn2.heads, head_dim=self.attn2.dim_head, mask=1, lk=ctx.s_ctx,
                                k_seq_stride=ctx.s_pad, v_seq_stride=ctx.s_pad, frames=g.n, ctx_batches=cb, batch0=cls)
+                    if MERGE_FRAMES:                         # ... i.e. ONE sequence of all the class's rows: full 128-query blocks (an image has
+                        akw.update(nseq=1, lq=g.n * (g.hw // cb), frames=1)      # 56 / 14 rows of a class at the two coarsest levels)
                     a = torch.empty((tv.shape[0], c), dtype=tv.dtype, device=tv.device)
                     fused = self.q2.fused()
                     if fused is not None and ops.attention_qproj_supported(tv, self.attn2.dim_head, 1):
