@@ -233,6 +233,11 @@ typedef struct TtAttnArgs {
   const void* wq; int64_t ldwq;
   const float* bq;
   int32_t qc; float ln_eps;
+  /* ABI 10.  v_rows != 0 (mask 0, head_dim 64, 16-bit dtype): `vt` holds V ITSELF -- [key rows, ldvt] (+ head*d), rows addressed like k
+   * (sequence s starts at row s * v_seq_stride) -- as it leaves a fused Q | K | V projection (nn.Linear to_q / to_k / to_v of
+   * BasicTransformerBlock.attn1 in ONE tt_gemm launch; transformer_temporal.py:353 via diffusers Attention): no V^T projection launch.
+   * The kernel transposes on the way out of LDS (ds_read_b64_tr_b16). */
+  int32_t v_rows;
 } TtAttnArgs;
 int tt_attention(const TtAttnArgs* args, tt_stream_t stream);
 

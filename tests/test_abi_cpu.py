@@ -26,7 +26,7 @@ def test_header_and_binding_agree(lib):
 
 
 def test_version_and_arch(lib):
-    assert lib.tt_abi_version() == 9
+    assert lib.tt_abi_version() == 10
     assert lib.tt_target_arch() == b"gfx950"
 
 

@@ -217,6 +217,28 @@ def test_attention_self(ops, dtype, l, heads, d):
 
 
 @pytest.mark.parametrize("dtype", DTYPES16)
+@pytest.mark.parametrize("l,heads", [(200, 2), (1792, 5), (448, 3), (28, 4), (65, 1)])
+def test_attention_self_with_v_as_rows(ops, dtype, l, heads):
+    """TtAttnArgs.v_rows (ABI 10): V read as it leaves a fused Q | K | V projection -- rows = keys, a column slice of a [M, 3C] tensor --
+    and transposed on the way out of LDS (ds_read_b64_tr_b16).  Same MFMA operands as the V^T route: the outputs must agree BIT FOR BIT,
+    ragged last key tiles included, and match fp32 SDPA."""
+    d, nseq = 64, 3
+    c = heads * d
+    q, k, v = (rnd(nseq, l, c, dtype=dtype, seed=s) for s in (1, 2, 3))
+    qkv = torch.cat([q, k, v], dim=2).reshape(nseq * l, 3 * c).cuda()
+    lp = (l + 7) // 8 * 8
+    vt = torch.zeros(c, nseq * lp, dtype=dtype)
+    vt.view(c, nseq, lp)[:, :, :l] = v.permute(2, 0, 1)
+    kw = dict(nseq=nseq, lq=l, heads=heads, head_dim=d, mask=0, lk=l, k_seq_stride=l)
+    out_t = torch.empty(nseq * l, c, dtype=dtype, device="cuda")
+    ops.attention(qkv[:, :c], qkv[:, c:2 * c], vt.cuda(), out_t, v_seq_stride=lp, **kw)
+    out_r = torch.empty(nseq * l, c, dtype=dtype, device="cuda")
+    ops.attention(qkv[:, :c], qkv[:, c:2 * c], qkv[:, 2 * c:], out_r, v_seq_stride=l, v_rows=True, **kw)
+    close(out_r.view(nseq, l, c), _sdpa(q, k, v, heads), dtype)
+    assert torch.equal(out_r, out_t), "row-major V must give the V^T route's output bit for bit"
+
+
+@pytest.mark.parametrize("dtype", DTYPES16)
 @pytest.mark.parametrize("l,heads,d", [(200, 2, 64), (1792, 1, 64), (448, 2, 64), (100, 1, 128)])
 def test_attention_fp8(ops, dtype, l, heads, d):
     """BASELINE config 5: spatial self-attention on OCP e4m3 operands (v_mfma_scale_f32_32x32x64_f8f6f4, unit scales), 16-bit output.

@@ -46,6 +46,7 @@ class TtAttnArgs(C.Structure):
         # ABI 6: fused query projection of the cross-attention (qx != NULL: Q = LN(qx rows) wq^T + bq computed by the kernel)
         ("qx", C.c_void_p), ("ldqx", C.c_int64), ("wq", C.c_void_p), ("ldwq", C.c_int64), ("bq", C.c_void_p),
         ("qc", C.c_int32), ("ln_eps", C.c_float),
+        ("v_rows", C.c_int32),              # ABI 10: `vt` is V itself, [key rows, ldvt]
     ]
 
 
@@ -131,7 +132,7 @@ def load():
     for name, (res, args) in SIGNATURES.items():
         fn = getattr(lib, name)          # AttributeError here == ABI mismatch with include/ttvdm.h
         fn.restype, fn.argtypes = res, args
-    if lib.tt_abi_version() != 9:
+    if lib.tt_abi_version() != 10:
         raise RuntimeError("libttvdm.so ABI version mismatch")
     _lib = lib
     return lib

@@ -28,6 +28,7 @@ struct AttnP {
   // fused query projection (cross-attention, round 4): Q = LN(x) Wq^T + bq computed by the block itself (QP instances)
   const char* qx; long ldqx; const char* wq; long ldwq; const float* bq; int qc; float ln_eps;
   unsigned qx_bytes, wq_bytes;
+  int v_rows;           // TtAttnArgs.v_rows: `vt` holds V itself, [key rows, ldvt] like k (VR instances)
 };
 
 constexpr int QB = 128;   // queries per block
@@ -87,8 +88,15 @@ __device__ __forceinline__ Bid3 xcd_remap3() {
 // 32 j + 8 g + 4 hi + e; registers g = 2t, 2t+1 of fragment j are the 8 contraction slots of key step 2j + t.  The caller
 // stores Wq / bq with bits 2 and 3 of the row index swapped inside every 16-row group (packing.permute_q_rows), so slot s of
 // half hi is head dimension 16 (2j + t) + 8 hi + s -- what the K fragment of that step holds.  No Q tensor, no separate launch.
-template <typename Tag, int D, int MASK, bool QP = false>
+// VR (spatial self-attention, D = 64, 16-bit storage): V arrives as it leaves the Q | K | V projection -- [key rows, ldvt], not transposed --
+// so the V projection needs no launch of its own with swapped operands.  The V tile is staged like the K tile ([64 keys][64 d], 128-byte rows,
+// same swizzle) and the d-major operand of O^T += V^T P^T comes out of it through ds_read_b64_tr_b16 (tools/tr_read_probe.hip: a 16-lane
+// group reads a [4 keys][16 d] block, lane i supplying the address of the 8-byte run (key i >> 2, d 4 (i & 3) ..) and receiving column i,
+// keys 0..3): two such reads give the 8 keys x 1 d a lane holds of an MFMA operand.  Two address registers per lane; tile half, key block
+// and d block are instruction offsets.
+template <typename Tag, int D, int MASK, bool QP = false, bool VR = false>
 __global__ __launch_bounds__(256, (D == 64 && Elem<Tag>::ES == 2) ? 2 : 1) void attn_kernel(const AttnP p) {
+  static_assert(!VR || (D == 64 && Elem<Tag>::ES == 2 && MASK == 0 && !QP), "row-major V: spatial self-attention, head dimension 64, 16-bit storage");
   kernarg_touch<sizeof(AttnP)>();
   extern __shared__ __attribute__((aligned(16))) char smem[];
   typedef typename Elem<Tag>::quad_t quad_t;
@@ -237,8 +245,13 @@ __global__ __launch_bounds__(256, (D == 64 && Elem<Tag>::ES == 2) ? 2 : 1) void 
   for (int i = 0; i < VPT; ++i) {
     const int slot = i * 256 + tid;
     const int r = slot / VCPR, c = (slot % VCPR) ^ tile_swz<VCPR>(r);
-    vc[i] = c * EPC;
-    vvo[i] = (int)(((long)(head * D + r) * p.ldvt + vbase + c * EPC) * ES);
+    if constexpr (VR) {                                      // rows = keys, like the K tile
+      vc[i] = r;
+      vvo[i] = (int)((((long)vbase + r) * p.ldvt + head * D + c * EPC) * ES);
+    } else {
+      vc[i] = c * EPC;
+      vvo[i] = (int)(((long)(head * D + r) * p.ldvt + vbase + c * EPC) * ES);
+    }
   }
   const int k_rows_left = p.k_rows_total - kbase;            // rows of K that exist from kbase on
   const long v_cols_left = p.vt_cols_total - vbase;
@@ -247,7 +260,7 @@ __global__ __launch_bounds__(256, (D == 64 && Elem<Tag>::ES == 2) ? 2 : 1) void 
     char* lk_ = smem + buf * STAGE + wid * 1024;
     char* lv_ = smem + buf * STAGE + K_BYTES + wid * 1024;
     const int soff_k = __builtin_amdgcn_readfirstlane((int)((long)j0 * p.ldk * ES));
-    const int soff_v = j0 * ES;
+    const int soff_v = VR ? __builtin_amdgcn_readfirstlane((int)((long)j0 * p.ldvt * ES)) : j0 * ES;
     const bool edge = j0 + KB > k_rows_left || j0 + KB > v_cols_left;    // uniform: only the last tile(s)
 #pragma unroll
     for (int i = 0; i < KPT; ++i) {
@@ -290,6 +303,15 @@ __global__ __launch_bounds__(256, (D == 64 && Elem<Tag>::ES == 2) ? 2 : 1) void 
 #pragma unroll
       for (int k = 0; k < 2 * PH; ++k) vaddr[db][k] = lds_base + tile_off<VCPR>(db * 32 + l31, (k / PH) * (32 / EPC) + hi * PH + k % PH);
   }
+  // VR: the two per-lane addresses of the transposing reads (tile half `half` of a fragment's 8 keys); see the kernel's header
+  unsigned vr_addr[2] = {0u, 0u};
+  if constexpr (VR) {
+    const int gi = lane & 15, gg = lane >> 4, r2 = gi >> 2;
+    const int base = ((gg & 1) * 2 + ((gi & 3) >> 1)) ^ ((gi >> 3) & 1);
+#pragma unroll
+    for (int half = 0; half < 2; ++half)
+      vr_addr[half] = lds_base + (gg >> 1) * 2048 + r2 * 128 + half * 512 + ((base ^ (half << 1)) << 4) + (gi & 1) * 8;
+  }
   auto k_addr = [&](int kb, int ds) -> unsigned {
     if constexpr (PRE) return kaddr[kb][ds]; else return lds_base + tile_off<KCPR>(kb * 32 + pi, ds * 2 + hi);
   };
@@ -321,6 +343,20 @@ __global__ __launch_bounds__(256, (D == 64 && Elem<Tag>::ES == 2) ? 2 : 1) void 
 #pragma unroll
       for (int j = 0; j < 4; ++j) f[j] = lds_read16_raw_off<VOFF>(v_addr(2 * (i / PH) + (j & 1), 2 * (i % PH) + (j >> 1)));
     };
+    // VR: fragment (db, k = kb * PH + h) = two transposing reads; offset = tile + key block kb (4096) + h (1024) + chunk bit 2 = db ^ h (64)
+    raw_u32x2_t ga[8], gb[8];
+    auto read_vr = [&](auto i_tag, raw_u32x2_t (&f)[8]) {
+      constexpr int I = decltype(i_tag)::value;
+      auto one = [&](auto j_tag) {
+        constexpr int J = decltype(j_tag)::value;
+        constexpr int db = 2 * (I / PH) + (J & 1), k = 2 * (I % PH) + (J >> 1), kb = k / PH, h = k % PH;
+        constexpr int off = VOFF + kb * 4096 + h * 1024 + ((db ^ h) << 6);
+        f[2 * J] = lds_read8_tr_off<off>(vr_addr[0]);
+        f[2 * J + 1] = lds_read8_tr_off<off>(vr_addr[1]);
+      };
+      one(std::integral_constant<int, 0>{}); one(std::integral_constant<int, 1>{});
+      one(std::integral_constant<int, 2>{}); one(std::integral_constant<int, 3>{});
+    };
     f32x16_t s[2];
 #pragma unroll
     for (int kb = 0; kb < 2; ++kb)
@@ -338,8 +374,13 @@ __global__ __launch_bounds__(256, (D == 64 && Elem<Tag>::ES == 2) ? 2 : 1) void 
       __builtin_amdgcn_sched_barrier(0);                       // the MFMAs read the batch before it is re-filled
       if (i + 2 < NBK) { if (i & 1) read_k(i + 2, fb); else read_k(i + 2, fa); }
     }
-    read_v(0, fa);
-    if constexpr (NBV > 1) read_v(1, fb);
+    if constexpr (VR) {
+      read_vr(std::integral_constant<int, 0>{}, ga);
+      read_vr(std::integral_constant<int, 1>{}, gb);
+    } else {
+      read_v(0, fa);
+      if constexpr (NBV > 1) read_v(1, fb);
+    }
     // ---- mask + online softmax (lane: one query, keys j0 + kb*32 + hi*16 + r).  Raw scores stay unscaled: the
     // 1/sqrt(d)*log2(e) factor c is folded into the exponent, p = exp2(s*c - m*c), one FMA per score.
     if constexpr (MASKED) {
@@ -394,6 +435,19 @@ __global__ __launch_bounds__(256, (D == 64 && Elem<Tag>::ES == 2) ? 2 : 1) void 
     }
     l_run += psum;
     // ---- O^T += Vt_tile * P^T : k-slot (hi, e) of read k = kb*PH + h is key kb*32 + 16*hi + EPC*h + e
+    if constexpr (VR) {                                        // (NBV = 2: both batches were requested before the softmax)
+#pragma unroll
+      for (int i = 0; i < NBV; ++i) {
+        if (i + 1 < NBV) lds_wait<8>(); else lds_wait<0>();
+        const raw_u32x2_t (&f)[8] = (i & 1) ? gb : ga;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          const int db = 2 * (i / PH) + (j & 1), k = 2 * (i % PH) + (j >> 1);
+          o[db] = Cvt<Tag>::mfma32(make_uint4(f[2 * j].x, f[2 * j].y, f[2 * j + 1].x, f[2 * j + 1].y), pf[k / PH][k % PH], o[db]);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+      }
+    } else {
 #pragma unroll
     for (int i = 0; i < NBV; ++i) {
       if (i + 1 < NBV) lds_wait<4>(); else lds_wait<0>();
@@ -405,6 +459,7 @@ __global__ __launch_bounds__(256, (D == 64 && Elem<Tag>::ES == 2) ? 2 : 1) void 
       }
       __builtin_amdgcn_sched_barrier(0);
       if (i + 2 < NBV) { if (i & 1) read_v(i + 2, fb); else read_v(i + 2, fa); }
+    }
     }
   };
 
@@ -724,6 +779,15 @@ void launch_attn(const AttnP& p, hipStream_t st) {
   if constexpr (D == 64 && Elem<Tag>::ES == 2) {
     if (p.qx) { if (p.mask == 1) launch_attn_qp<Tag, 1>(p, st); else launch_attn_qp<Tag, 2>(p, st); return; }
   }
+  if constexpr (D == 64 && Elem<Tag>::ES == 2) {
+    if (p.v_rows) {                                          // row-major V (mask 0, checked by tt_attention)
+      constexpr size_t lds = 2 * (KB * D * 2 + D * KB * 2);
+      static unsigned long long attr_done = 0;
+      tt_lds_opt_in((const void*)attn_kernel<Tag, 64, 0, false, true>, (int)lds, &attr_done);
+      hipLaunchKernelGGL((attn_kernel<Tag, 64, 0, false, true>), dim3((p.lq + QB - 1) / QB, p.heads, p.nseq), dim3(256), lds, st, p);
+      return;
+    }
+  }
   if (p.mask == 0) launch_attn_m<Tag, D, 0>(p, st);
   else if (p.mask == 1) launch_attn_m<Tag, D, 1>(p, st);
   else launch_attn_m<Tag, D, 2>(p, st);
@@ -929,7 +993,7 @@ extern "C" int tt_attention(const TtAttnArgs* a, tt_stream_t stream) {
   if (a->fp8 && (a->mask != 0 || a->dtype == TT_F32)) TT_FAIL(TT_EUNSUPPORTED, "tt_attention: the fp8 path serves spatial self-attention (mask 0) with 16-bit output");
   const int es = a->fp8 ? 1 : (a->dtype == TT_F32 ? 4 : 2);      // bytes per q/k/vt element
   const int eso = a->dtype == TT_F32 ? 4 : 2;
-  if ((a->q && ((a->ldq * es) & 15)) || ((a->ldk * es) & 15) || ((a->ldvt * es) & 15) || ((a->ldo * eso) & 15) || ((a->v_seq_stride * es) & 15))
+  if ((a->q && ((a->ldq * es) & 15)) || ((a->ldk * es) & 15) || ((a->ldvt * es) & 15) || ((a->ldo * eso) & 15) || (!a->v_rows && ((a->v_seq_stride * es) & 15)))
     TT_FAIL(TT_EINVAL, "tt_attention: strides must keep 16-byte chunks aligned");
   AttnP p;
   p.q = (const char*)a->q; p.ldq = a->ldq; p.k = (const char*)a->k; p.ldk = a->ldk;
@@ -939,10 +1003,15 @@ extern "C" int tt_attention(const TtAttnArgs* a, tt_stream_t stream) {
   const int nctx = a->mask == 0 ? a->nseq : a->ctx_batches;
   p.k_rows_total = nctx * a->k_seq_stride;
   p.vt_cols_total = (long)nctx * a->v_seq_stride;
-  if (p.vt_cols_total > a->ldvt) TT_FAIL(TT_EINVAL, "tt_attention: ldvt smaller than the key columns");
+  p.v_rows = a->v_rows ? 1 : 0;
+  if (a->v_rows && (a->mask != 0 || a->head_dim != 64 || a->dtype == TT_F32 || a->fp8 || a->qx))
+    TT_FAIL(TT_EUNSUPPORTED, "tt_attention: v_rows (V not transposed) serves spatial self-attention (mask 0), head_dim 64, 16-bit storage");
+  if (!a->v_rows && p.vt_cols_total > a->ldvt) TT_FAIL(TT_EINVAL, "tt_attention: ldvt smaller than the key columns");
+  if (a->v_rows && a->ldvt < (long)a->heads * a->head_dim) TT_FAIL(TT_EINVAL, "tt_attention: v_rows needs ldvt >= heads * head_dim");
   {
     const long kb = ((long)(p.k_rows_total - 1) * a->ldk + (long)a->heads * a->head_dim) * es;
-    const long vb = ((long)(a->heads * a->head_dim - 1) * a->ldvt + p.vt_cols_total) * es;
+    const long vb = a->v_rows ? ((long)(p.vt_cols_total - 1) * a->ldvt + (long)a->heads * a->head_dim) * es
+                              : ((long)(a->heads * a->head_dim - 1) * a->ldvt + p.vt_cols_total) * es;
     if (kb >= (1L << 31) || vb >= (1L << 31)) TT_FAIL(TT_EUNSUPPORTED, "tt_attention: K or V^T larger than 2 GiB");
     p.k_bytes = (unsigned)kb; p.vt_bytes = (unsigned)vb;
   }

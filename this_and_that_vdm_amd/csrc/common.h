@@ -236,6 +236,14 @@ template <int OFF> __device__ __forceinline__ raw_u32x4_t lds_read16_raw_off(uns
   else asm volatile("ds_read_b128 %0, %1" : "=v"(v) : "v"(addr + (unsigned)OFF));     // beyond the 16-bit field (fp32, D = 128)
   return v;
 }
+// gfx950's transposing read (ds_read_b64_tr_b16): a 16-lane group reads a [4 rows][16 columns] block of 16-bit elements, lane i supplying the
+// address of the 8-byte run (row i >> 2, columns 4 (i & 3) ..), and lane i receives column i, rows 0..3 (tools/tr_read_probe.hip)
+template <int OFF> __device__ __forceinline__ raw_u32x2_t lds_read8_tr_off(unsigned addr) {
+  static_assert(OFF >= 0 && OFF < 65536, "offset");
+  raw_u32x2_t v;
+  asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "=v"(v) : "v"(addr), "n"(OFF));
+  return v;
+}
 __device__ __forceinline__ raw_u32x2_t lds_read8_raw(unsigned addr) {
   raw_u32x2_t v;
   asm volatile("ds_read_b64 %0, %1" : "=v"(v) : "v"(addr));

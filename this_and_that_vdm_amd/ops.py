@@ -238,9 +238,10 @@ def attention_qproj_supported(x, head_dim: int, mask: int) -> bool:
 
 
 def attention(q, k, vt, out, *, nseq, lq, heads, head_dim, mask, lk, k_seq_stride, v_seq_stride, frames=1, ctx_batches=1,
-              batch0=0, qx=None, wq=None, bq=None, ln_eps: float = 1e-5):
+              batch0=0, qx=None, wq=None, bq=None, ln_eps: float = 1e-5, v_rows: bool = False):
     """q [nseq*lq, heads*d] -- or q=None with qx / wq / bq: the kernel computes Q = LN(qx rows) wq^T + bq itself (cross-attention,
-    d = 64, 16-bit; wq / bq LayerNorm-folded and row-permuted by packing.permute_q_rows)."""
+    d = 64, 16-bit; wq / bq LayerNorm-folded and row-permuted by packing.permute_q_rows).
+    v_rows: `vt` is V itself, [key rows, heads*d] (e.g. a column slice of a fused Q | K | V projection): mask 0, d = 64, 16-bit."""
     lib = _lib.load()
     a = TtAttnArgs()
     if qx is not None:
@@ -262,11 +263,12 @@ def attention(q, k, vt, out, *, nseq, lq, heads, head_dim, mask, lk, k_seq_strid
     if fp8 and not (k.dtype == FP8 and vt.dtype == FP8):
         raise RuntimeError("fp8 attention needs q, k and vt in torch.float8_e4m3fn")
     a.frames, a.ctx_batches, a.dtype, a.batch0, a.fp8 = frames, ctx_batches, _code(out.dtype if fp8 else q.dtype), batch0, int(fp8)
+    a.v_rows = int(bool(v_rows))
     ev = _prof_begin()
     check(lib.tt_attention(C.byref(a), _stream()), "tt_attention")
     if ev is not None:
         tag = _TAG[a.dtype]
-        kname = f"attn8_kernel<{tag}, {head_dim}>" if fp8 else f"attn_kernel<{tag}, {head_dim}, {mask}{', true' if qx is not None else ''}>"
+        kname = f"attn8_kernel<{tag}, {head_dim}>" if fp8 else f"attn_kernel<{tag}, {head_dim}, {mask}{', true' if qx is not None else ''}{', false, true' if v_rows else ''}>"
         flops = 4.0 * nseq * heads * lq * lk * head_dim + (2.0 * nseq * lq * heads * head_dim * qx.shape[1] if qx is not None else 0.0)
         _prof_end(ev, kname, flops, shape=("attn", nseq * heads, lq, lk, mask, 0))
     return out

@@ -23,6 +23,7 @@ from ..packing import fold_layernorm, pack_conv1x1, pack_conv3x3, pack_geglu, pa
 
 
 ZERO_CTX_TEMPORAL = os.environ.get("TT_ZERO_CTX_T", "1") != "0"      # A/B switch of the temporal zero-context shortcut
+ATTN_V_ROWS = os.environ.get("TT_ATTN_V_ROWS", "1") != "0"            # spatial self-attention from ONE Q | K | V launch, V not transposed (tt_attention v_rows)
 MERGE_FRAMES = os.environ.get("TT_XATTN_MERGE_FRAMES", "1") != "0"    # spatial cross-attention: the frames of a batch element as one sequence (A/B)
 
 
@@ -470,11 +471,18 @@ class FeedForward(_Packable):
         return ops.gemm(hid, self.w2, bias=self.b2, residual=residual, blend=blend, alpha=alpha, rowvec=rowvec, rowvec_rows=rowvec_rows)
 
 
-def _self_attention(x, attn: Attention, wqk, bqk, wv, eps, g: Geom, ctx: StepContext):
+def _self_attention(x, attn: Attention, wqk, bqk, wv, eps, g: Geom, ctx: StepContext, wqkv=None, bqkv=None):
     """spatial self-attention over hw tokens per frame on the UN-normalised hidden states: norm1 is folded into the QK
-    projection (rows) and into the swapped V^T projection (columns); flash kernel."""
+    projection (rows) and into the swapped V^T projection (columns); flash kernel.
+    wqkv / bqkv (16-bit storage, head dimension 64, not the fp8 path): ONE Q | K | V projection launch and the attention kernel reads V
+    as it is (tt_attention v_rows: transposed on the way out of LDS) -- no V^T projection launch."""
     c = attn.inner_dim
     fp8 = ctx.attn_fp8 and x.dtype != torch.float32
+    if wqkv is not None and not fp8 and ATTN_V_ROWS and attn.dim_head == 64 and x.dtype in (torch.float16, torch.bfloat16):
+        qkv = ops.gemm(x, wqkv, bias=bqkv, ln_fold=1, ln_eps=eps)         # [M, 3C]
+        out = torch.empty((g.m, c), dtype=x.dtype, device=x.device)
+        return ops.attention(qkv[:, :c], qkv[:, c:2 * c], qkv[:, 2 * c:], out, nseq=g.n, lq=g.hw, heads=attn.heads, head_dim=attn.dim_head,
+                             mask=0, lk=g.hw, k_seq_stride=g.hw, v_seq_stride=g.hw, v_rows=True)
     pad = 16 if fp8 else 8                                                # V^T sequences start on 16-byte chunks
     hwp = (g.hw + pad - 1) // pad * pad
     vt = ctx.vt_buffer(c, g.n * hwp, x, ops.FP8 if fp8 else None)
@@ -555,8 +563,11 @@ class BasicTransformerBlock(_Packable):
         wq, bq = fold_layernorm(self.attn1.to_q.weight, None, n1.weight, n1.bias)
         wk, bk = fold_layernorm(self.attn1.to_k.weight, None, n1.weight, n1.bias)
         wv, bv = fold_layernorm(self.attn1.to_v.weight, None, n1.weight, n1.bias)
-        self.wqk, self.bqk = zr(torch.cat([wq, wk], 0)), torch.cat([bq, bk], 0).contiguous()
-        self.wv = zr(wv)
+        # one [3C, C] matrix: Q | K rows first (the two-launch route reads them as a view), V rows last; V has no bias of its own (below)
+        self.wqkv = zr(torch.cat([wq, wk, wv], 0))
+        self.bqkv = torch.cat([bq, bk, torch.zeros_like(bq)], 0).contiguous()
+        c2 = 2 * wq.shape[0]
+        self.wqk, self.bqk, self.wv = self.wqkv[:c2], self.bqkv[:c2], self.wqkv[c2:]
         self.wo1 = cv(self.attn1.to_out[0].weight)
         self.bo1 = (_f32(self.attn1.to_out[0].bias) + self.wo1.float() @ bv).contiguous()
         wq2, bq2 = fold_layernorm(self.attn2.to_q.weight, None, n2.weight, n2.bias)
@@ -583,7 +594,7 @@ class BasicTransformerBlock(_Packable):
         """out_rowvec fp32 [N, C] (one row per frame of the batch): added to the block's output -- the frame-position embedding the
         temporal block that follows would otherwise add in a pass of its own (TransformerSpatioTemporalModel.forward)."""
         ff_rv = dict(rowvec=out_rowvec, rowvec_rows=g.hw) if out_rowvec is not None else {}
-        a = _self_attention(x, self.attn1, self.wqk, self.bqk, self.wv, self.norm1.eps, g, ctx)
+        a = _self_attention(x, self.attn1, self.wqk, self.bqk, self.wv, self.norm1.eps, g, ctx, self.wqkv, self.bqkv)
         live = ctx.live_batches(g)
         if live is None:
             x = ops.gemm(a, self.wo1, bias=self.bo1, residual=x)
