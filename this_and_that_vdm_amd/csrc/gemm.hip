@@ -120,11 +120,11 @@ Plan make_plan(int m, int n, long ktot, bool allow_split, bool wide_ok = true, b
     // third level, everything K = C at the coarsest one) on 64 x 64 tiles, two blocks per CU, all resident at once: faster on warm operands
     // (tools/small_gemm_sweep.py, us in a graph of ten launches: 1568 x 1280 x 1280 16.8 -> 12.3, 784 rows 16.6 -> 11.3, 392 rows 13.7 -> 10.0),
     // NOT in the step, where every weight comes from HBM once and 64-row tiles fetch it twice as often: 29.06 / 29.18 -> 29.10 / 29.10 ms
-    // (one call, interleaved).  Opt-in: TT_GEMM_SMALL64=1.  Default (2): only problems of at most 64 rows -- the 64-row tail of the third level's
+    // (one call, interleaved).  Opt-in: TT_GEMM_SMALL64=1.  Default (2): only wide problems (n >= 4096) of at most 64 rows -- the 64-row tail of the third level's
     // GEGLU projection (3136 = 12 x 256 + 64 rows; 21 launches per step), half of whose 128-row tiles was padding: 29.78 / 29.76 -> 29.70 / 29.67 ms.
     static int small64 = -1;
     if (small64 < 0) { const char* e = getenv("TT_GEMM_SMALL64"); small64 = e ? atoi(e) : 2; }
-    if (small64 && (small64 != 2 || m <= 64) && mode0 && ktot <= 2048 && (long)ceil_div(m, 64) * ceil_div(n, 64) <= 512) { pl.cfg = 2; return pl; }   // (2: only the <= 64-row tails)
+    if (small64 && (small64 != 2 || (m <= 64 && n >= 4096)) && mode0 && ktot <= 2048 && (long)ceil_div(m, 64) * ceil_div(n, 64) <= 512) { pl.cfg = 2; return pl; }   // (2: only the <= 64-row tails)
     pl.cfg = (deep == 2 && k128) ? 20 : 16;
     long s = allow_split ? 256 / b128 : 1;
     if (s > kt / 8) s = kt / 8;
