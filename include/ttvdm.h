@@ -300,6 +300,13 @@ int tt_layernorm(const void* x, int64_t ldx, int32_t rows, int32_t c, const floa
  *   y[r][n] = act_out( sum_k act_in(x[r][k]) * W[n][k] + bias[n] ),  act: 0 none, 1 SiLU.
  * W is `dtype`, x/y/bias fp32.  accumulate != 0 adds into y.
  * ---------------------------------------------------------------------------------------------- */
+/* Weight packing on the device (packing.zero_sum_round; the LayerNorm-folded projections of Basic / TemporalBasicTransformerBlock reached
+ * from transformer_temporal.py:342-365): rounds the rows of w (fp32 [n, k], each summing to ~0) to the 16-bit `dtype` such that every ROUNDED
+ * row sums to exactly zero -- binade by binade from `hi` down to max(lo, hi - 48) (the largest / smallest binade exponent of the rounded
+ * non-zero values of the whole matrix), up to round(|row sum| / ulp) elements of a binade move by one ulp.  One block per row; the result is
+ * bit-identical to the host implementation.  k <= 16384. */
+int tt_zero_sum_round(const float* w, int64_t ldw, int32_t n, int32_t k, int32_t hi, int32_t lo, void* out, int64_t ldo,
+                      int32_t dtype, tt_stream_t stream);
 int tt_small_linear(const float* x, int64_t ldx, int32_t rows, int32_t k, const void* w, int64_t ldw, int32_t n,
                     const float* bias, int32_t act_in, int32_t act_out, int32_t accumulate, float* y, int64_t ldy,
                     int32_t dtype, tt_stream_t stream);

@@ -217,6 +217,42 @@ def test_attention_self(ops, dtype, l, heads, d):
 
 
 @pytest.mark.parametrize("dtype", DTYPES16)
+@pytest.mark.parametrize("n,k,kind", [(960, 320, "normal"), (2560, 1280, "normal"), (640, 640, "wide"), (37, 200, "wide"), (64, 8, "normal"),
+                                      (16, 5120, "wide"), (128, 320, "zeros"), (8, 1000, "tiny")])
+def test_zero_sum_round_on_the_device_matches_the_host_version(ops, dtype, n, k, kind):
+    """tt_zero_sum_round (one block per row) against packing.zero_sum_round's tensor passes: the packed weights must be identical value for value (= bit for bit except the sign of a zero) --
+    wide binade ranges, rows with zeros, all-zero rows, magnitudes near the storage type's subnormals -- and every row must sum to (almost) zero."""
+    from this_and_that_vdm_amd import packing
+    g = torch.Generator().manual_seed(n * 7919 + k)
+    w = torch.randn(n, k, generator=g) * k ** -0.5
+    if kind == "wide":
+        w = w * torch.exp2(torch.randint(-14, 3, (n, k), generator=g).float())
+    if kind == "zeros":
+        w[torch.rand(n, k, generator=g) < 0.3] = 0.0
+        w[3] = 0.0
+    if kind == "tiny":
+        w = w * (1e-37 if dtype == torch.bfloat16 else 3e-6)
+    w = (w - w.mean(1, keepdim=True)).float()
+    keep = packing.DEVICE_ROUNDING
+    try:
+        packing.DEVICE_ROUNDING = True
+        dev = packing.zero_sum_round(w.cuda(), dtype)
+        packing.DEVICE_ROUNDING = False
+        host = packing.zero_sum_round(w.cuda(), dtype)
+        cpu = packing.zero_sum_round(w, dtype)
+    finally:
+        packing.DEVICE_ROUNDING = keep
+    assert dev.dtype == dtype and dev.is_cuda
+    # (value equality: for non-zero 16-bit values that is bit equality; a weight that underflows to -0 keeps its sign on the device while the
+    # host's `q - 0 * (-u)` turns it into +0 -- the same number)
+    assert torch.equal(dev.cpu(), cpu), "device kernel differs from the host algorithm"
+    assert torch.equal(host.cpu(), cpu)
+    if k >= 64:                                               # (a row of 8 elements has too few candidates to cancel every residual)
+        plain = w.to(dtype).double().sum(1).abs().max()
+        assert float(dev.double().sum(1).abs().max()) <= max(float(plain) * 1e-2, 1e-30)
+
+
+@pytest.mark.parametrize("dtype", DTYPES16)
 @pytest.mark.parametrize("l,heads", [(200, 2), (1792, 5), (448, 3), (28, 4), (65, 1)])
 def test_attention_self_with_v_as_rows(ops, dtype, l, heads):
     """TtAttnArgs.v_rows (ABI 10): V read as it leaves a fused Q | K | V projection -- rows = keys, a column slice of a [M, 3C] tensor --

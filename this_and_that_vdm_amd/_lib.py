@@ -91,6 +91,7 @@ SIGNATURES = {
     "tt_gemm_stats_rows": (C.c_int32, [C.POINTER(TtGemmArgs)]),
     "tt_gemm_gn_fused": (C.c_int32, [C.POINTER(TtGemmArgs)]),
     "tt_layernorm": (C.c_int, [_vp, _i64, _i32, _i32, _vp, _vp, _f32, _vp, _i32, _i32, _vp, _vp, _i64, _i32, _vp]),
+    "tt_zero_sum_round": (C.c_int, [_vp, _i64, _i32, _i32, _i32, _i32, _vp, _i64, _i32, _vp]),
     "tt_small_linear": (C.c_int, [_vp, _i64, _i32, _i32, _vp, _i64, _i32, _vp, _i32, _i32, _i32, _vp, _i64, _i32, _vp]),
     "tt_timestep_embedding": (C.c_int, [_vp, _i32, _i32, _vp, _i64, _vp]),
     "tt_prep_model_input": (C.c_int, [_vp, _vp, _vp, _vp, _i32, _i32, _i32, _i32, _i32, _i32, _vp, _i32, _vp]),

@@ -1,4 +1,5 @@
 // Small dense layers on a handful of rows, sinusoidal embeddings, denoise-loop glue and layout plumbing.
+#include <type_traits>
 #include "common.h"
 
 namespace {
@@ -54,6 +55,85 @@ __global__ __launch_bounds__(256) void small_linear_kernel(const float* x, long 
       }
     }
   }
+}
+
+// packing.zero_sum_round on the device: one block per weight row (the host version is ~50 passes of fp64 tensor kernels over every
+// LayerNorm-folded matrix: 2.4-2.9 s per process).  Same algorithm, same result bit for bit: q = w rounded to the storage type; r = sum(q)
+// (fp64, exact: dyadic terms); binade by binade from the coarsest (`hi`, matrix-wide) down, up to round(|r| / u) elements of the binade --
+// the first ones in index order -- move one ulp u against the sign of r; first descent: only elements whose own rounding went that way
+// (their other rounding neighbour), second: any element not moved yet.  LDS: the row as fp32 (16-bit values are exact in fp32), its
+// binade exponents and flags.  Thread t owns the contiguous elements [t E, (t + 1) E): "the first n" is a block-wide exclusive scan.
+template <typename Tag>
+__global__ __launch_bounds__(256) void zero_sum_round_kernel(const float* w, long ldw, int k, int hi, int lo, char* out, long ldo) {
+  extern __shared__ __attribute__((aligned(16))) char zs_smem[];
+  float* q = (float*)zs_smem;                                   // [k]
+  short* ex = (short*)(q + k);                                  // [k] binade exponent
+  unsigned char* fl = (unsigned char*)(ex + k);                 // [k] bit 0 rounded up, 1 rounded down, 2 non-zero, 3 moved
+  __shared__ double red[4];
+  __shared__ int cnts[5];
+  constexpr int mant = std::is_same<Tag, bf16_tag>::value ? 7 : 10, emin = std::is_same<Tag, bf16_tag>::value ? -126 : -14;
+  const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+  const long row = blockIdx.x;
+  const int E = (k + 255) / 256, i0 = tid * E, i1 = min(k, i0 + E);
+  double rs = 0.0;
+  for (int i = i0; i < i1; ++i) {
+    const float x = w[row * ldw + i];
+    const float v = round_store<Tag>(x);
+    q[i] = v;
+    int e = v != 0.f ? ilogbf(fabsf(v)) : -1;
+    if (e < emin) e = emin;
+    ex[i] = (short)e;
+    fl[i] = (unsigned char)((v > x ? 1 : 0) | (v < x ? 2 : 0) | (v != 0.f ? 4 : 0));
+    rs += (double)v;
+  }
+  // exact row sum: lanes by shuffle, waves through LDS (all terms dyadic: the order does not matter)
+  auto block_sum = [&](double v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+    __syncthreads();
+    if (lane == 0) red[wv] = v;
+    __syncthreads();
+    return (red[0] + red[1]) + (red[2] + red[3]);
+  };
+  double r = block_sum(rs);
+  const int stop = lo > hi - 48 ? lo : hi - 48;
+  for (int pass = 0; pass < 2; ++pass) {
+    for (int lvl = hi; lvl >= stop; --lvl) {
+      if (r == 0.0) break;                                     // (uniform: every thread holds the same r)
+      const double u = ldexp(1.0, lvl - mant);
+      const double want = fabs(rint(r / u));
+      if (want == 0.0) continue;
+      const unsigned char need = pass == 0 ? (r > 0.0 ? 1 : 2) : 0;    // first descent: rounded up (r > 0) / down (r <= 0) elements only
+      int c = 0;
+      for (int i = i0; i < i1; ++i) {
+        const unsigned char f = fl[i];
+        c += ((f & 4) && !(f & 8) && ex[i] == lvl && (!need || (f & need))) ? 1 : 0;
+      }
+      // exclusive scan of the per-thread counts in thread order
+      int incl = c;
+#pragma unroll
+      for (int o = 1; o < 64; o <<= 1) { const int t = __shfl_up(incl, o); if (lane >= o) incl += t; }
+      __syncthreads();
+      if (lane == 63) cnts[wv] = incl;
+      __syncthreads();
+      int base = incl - c;
+      for (int w2 = 0; w2 < wv; ++w2) base += cnts[w2];
+      const int total = cnts[0] + cnts[1] + cnts[2] + cnts[3];
+      const double nabs = want < (double)total ? want : (double)total;
+      const int n = (int)nabs;
+      const float step = (float)(r > 0.0 ? u : -u);            // q -= sign(n) u
+      int rank = base;
+      for (int i = i0; i < i1; ++i) {
+        const unsigned char f = fl[i];
+        if ((f & 4) && !(f & 8) && ex[i] == lvl && (!need || (f & need))) {
+          if (rank < n) { q[i] -= step; fl[i] = f | 8; }
+          ++rank;
+        }
+      }
+      r -= (r > 0.0 ? nabs : -nabs) * u;
+    }
+  }
+  for (int i = i0; i < i1; ++i) store1<Tag>(out + (row * ldo + i) * 2, q[i]);
 }
 
 __global__ void timestep_embedding_kernel(const float* t, int rows, int dim, float* out, long ldo) {
@@ -299,6 +379,25 @@ extern "C" int tt_small_linear(const float* x, int64_t ldx, int32_t rows, int32_
   else
     hipLaunchKernelGGL((small_linear_kernel<f32_tag, 4>), grid, block, lds, st, x, (long)ldx, rows, k, (const char*)w, (long)ldw, n, bias, act_in, act_out, accumulate, y, (long)ldy);
   TT_CHECK_LAUNCH("tt_small_linear");
+  return TT_OK;
+}
+
+extern "C" int tt_zero_sum_round(const float* w, int64_t ldw, int32_t n, int32_t k, int32_t hi, int32_t lo, void* out, int64_t ldo,
+                                 int32_t dtype, tt_stream_t stream) {
+  if (!w || !out || n <= 0 || k <= 0) TT_FAIL(TT_EINVAL, "tt_zero_sum_round: bad arguments");
+  if (dtype != TT_BF16 && dtype != TT_F16) TT_FAIL(TT_EINVAL, "tt_zero_sum_round: 16-bit storage types only");
+  if (k > 16384) TT_FAIL(TT_EUNSUPPORTED, "tt_zero_sum_round: k = %d > 16384 (a row lives in LDS)", k);
+  const size_t lds = (size_t)k * 7;                          // fp32 value + 16-bit exponent + flag byte
+  hipStream_t st = (hipStream_t)stream;
+  static unsigned long long attr_done[2] = {0, 0};
+  if (dtype == TT_BF16) {
+    tt_lds_opt_in((const void*)zero_sum_round_kernel<bf16_tag>, 7 * 16384, &attr_done[0]);
+    hipLaunchKernelGGL(zero_sum_round_kernel<bf16_tag>, dim3(n), dim3(256), lds, st, w, (long)ldw, k, hi, lo, (char*)out, (long)ldo);
+  } else {
+    tt_lds_opt_in((const void*)zero_sum_round_kernel<f16_tag>, 7 * 16384, &attr_done[1]);
+    hipLaunchKernelGGL(zero_sum_round_kernel<f16_tag>, dim3(n), dim3(256), lds, st, w, (long)ldw, k, hi, lo, (char*)out, (long)ldo);
+  }
+  TT_CHECK_LAUNCH("tt_zero_sum_round");
   return TT_OK;
 }
 
