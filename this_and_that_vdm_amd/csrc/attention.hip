@@ -67,6 +67,12 @@ __device__ __forceinline__ float fast_exp2(float x) { return __builtin_amdgcn_ex
 // XCD runs a CONTIGUOUS range of logical blocks, x fastest -- the query blocks of one (head, sequence) then share an XCD and its
 // L2 keeps their K / V^T (every query block streams all of them) instead of all eight L2s fetching a copy through the fabric.
 struct Bid3 { int x, y, z; };
+// HEADFAST (the fused-query cross-attention, whose large operand is the block's x rows, not the 78-token context): heads fastest, so the
+// heads of one query block run on one XCD next to each other and its L2 serves the x tile to all but the first (TT_ATTN_QP_HEADFAST=0: A/B build)
+#ifndef TT_ATTN_QP_HEADFAST
+#define TT_ATTN_QP_HEADFAST 1
+#endif
+template <bool HEADFAST = false>
 __device__ __forceinline__ Bid3 xcd_remap3() {
   const int gx = gridDim.x, gy = gridDim.y;
   const int nwg = gx * gy * (int)gridDim.z;
@@ -74,10 +80,17 @@ __device__ __forceinline__ Bid3 xcd_remap3() {
   const int q = nwg >> 3, r = nwg & 7, xcd = bid & 7, idx = bid >> 3;
   bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
   Bid3 o;
-  o.x = bid % gx;
-  const int t = bid / gx;
-  o.y = t % gy;
-  o.z = t / gy;
+  if constexpr (HEADFAST) {
+    o.y = bid % gy;
+    const int t = bid / gy;
+    o.x = t % gx;
+    o.z = t / gx;
+  } else {
+    o.x = bid % gx;
+    const int t = bid / gx;
+    o.y = t % gy;
+    o.z = t / gy;
+  }
   return o;
 }
 
@@ -114,7 +127,7 @@ __global__ __launch_bounds__(256, (D == 64 && Elem<Tag>::ES == 2) ? 2 : 1) void 
   const int tid = threadIdx.x, lane = tid & 63;
   const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int l31 = lane & 31, hi = lane >> 5;
-  const Bid3 blk = xcd_remap3();
+  const Bid3 blk = xcd_remap3<QP && TT_ATTN_QP_HEADFAST>();
   const int head = blk.y, seq = blk.z;
   const char* zero = (const char*)tt_zero_page;
 
