@@ -24,6 +24,28 @@ def bench(nseq, heads, L, d, dtype=torch.bfloat16, iters=10):
 
 for args in ((28, 5, 1792, 64), (28, 10, 448, 64), (28, 20, 112, 64), (28, 5, 7168, 64), (28, 10, 1792, 64), (28, 20, 448, 64), (28, 10, 1792, 128)):
     bench(*args)
+
+
+def bench_vr(nseq, heads, L, d=64, dtype=torch.bfloat16, iters=10):
+    """the same problem with V read as rows of a fused Q | K | V tensor (TtAttnArgs.v_rows: transposed on the way out of LDS)"""
+    c = heads * d
+    qkv = torch.randn(nseq * L, 3 * c, device="cuda", dtype=dtype)
+    out = torch.empty(nseq * L, c, device="cuda", dtype=dtype)
+    f = lambda: ops.attention(qkv[:, :c], qkv[:, c:2 * c], qkv[:, 2 * c:], out, nseq=nseq, lq=L, heads=heads, head_dim=d, mask=0, lk=L,
+                              k_seq_stride=L, v_seq_stride=L, v_rows=True)
+    for _ in range(3): f()
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(iters): f()
+    e1.record(); torch.cuda.synchronize()
+    s = e0.elapsed_time(e1) / iters * 1e-3
+    fl = 4.0 * nseq * heads * L * L * d
+    print(f"nseq {nseq:3d} heads {heads:2d} L {L:5d} d {d:3d} V as rows: {s*1e6:9.1f} us  {fl/s/1e12:7.1f} TFLOP/s  ({fl/s/2.5e15*100:4.1f} % of 2.5 PF)")
+
+
+for args in ((28, 5, 1792), (28, 10, 448), (28, 20, 112), (28, 5, 7168)):
+    bench_vr(*args)
 bench(28, 5, 7168, 64, torch.float16)
 
 def bench8(nseq, heads, L, d, iters=10):
