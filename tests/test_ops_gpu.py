@@ -431,9 +431,12 @@ def test_attention_fused_query_projection(ops, dtype, c, heads, b, f, hw, s, str
 
 
 @pytest.mark.parametrize("dtype", DTYPES)
-@pytest.mark.parametrize("frames,heads,d", [(14, 3, 64), (4, 1, 64), (25, 2, 64), (3, 2, 128)])
-def test_temporal_self_attention(ops, dtype, frames, heads, d):
-    b, hw, c = 2, 19, heads * d
+@pytest.mark.parametrize("frames,heads,d,hw", [(14, 3, 64, 19), (4, 1, 64, 19), (25, 2, 64, 19), (3, 2, 128, 19), (16, 5, 64, 19), (1, 2, 64, 7),
+                                               (14, 5, 64, 1100)])        # (the last one: 11 000 units -- more than one grid-stride round of the MFMA kernel)
+def test_temporal_self_attention(ops, dtype, frames, heads, d, hw):
+    """tt_temporal_attention against fp32 SDPA over the frame axis: the matrix-core kernel (16-bit storage, head dimension 64, <= 16 frames:
+    16 x 16 x 32 MFMAs, V transposed on the way out of LDS) and the per-lane kernel (everything else)."""
+    b, c = 2, heads * d
     qkv = rnd(b * frames * hw, 3 * c, dtype=dtype, seed=1)
     out = torch.empty(b * frames * hw, c, dtype=dtype, device="cuda")
     ops.temporal_attention(qkv.cuda(), out, batch=b, frames=frames, hw=hw, heads=heads, head_dim=d)

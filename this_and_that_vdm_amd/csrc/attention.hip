@@ -964,6 +964,92 @@ __global__ __launch_bounds__(128) void tattn_kernel(const char* qkv, long ldqkv,
   for (int c = 0; c < D / EPC; ++c) *(uint4*)(op + c * 16) = pack_chunk<Tag>(acc + c * EPC);
 }
 
+// ---- the same on the matrix cores (16-bit storage, D = 64, frames <= 16): one wave per unit (batch, pixel, head), 16 x 16 x 32 MFMAs.
+//   S^T = K Q^T: lane (i = lane & 15, g = lane >> 4) loads 2 x 16 bytes of K row i and of Q row i -- head dimensions 8 g .. (its slots of k-step 0)
+//   and 32 + 8 g .. (k-step 1), four lanes per 64 contiguous bytes -- straight from HBM into the operand registers.  The lane
+//   then holds the scores of query column lane & 15 against keys 4 g .. 4 g + 3: softmax = 3 in-lane steps + the lane exchanges xor 16, xor 32.
+//   O^T = V^T P^T: the probabilities a lane holds ARE its B operand (keys 4 g .. 4 g + 3 in slots 0..3, slots 4..7 zero); V goes through a
+//   per-wave LDS tile [16 frames][64 d] and comes back transposed by ds_read_b64_tr_b16 -- group g reads the [4 keys][16 d] block of keys
+//   4 g .., i.e. exactly the 4 slots of the matching A operand (the other 4 zero).  6 MFMAs and ~40 VALU per unit instead of ~1 300 VALU per lane.
+template <typename Tag>
+__global__ __launch_bounds__(256) void tattn_mfma_kernel(const char* qkv, long ldqkv, char* out, long ldo, int batch, int frames, int hw, int heads,
+                                                         float scale_log2e, long total_units) {
+  typedef float f32x4v __attribute__((ext_vector_type(4)));
+  __shared__ __attribute__((aligned(16))) char vbuf[4][16 * 144];
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  const int i = lane & 15, g = lane >> 4;
+  const int C = heads * 64;
+  const unsigned vb = lds_addr(vbuf[wv]);
+  const unsigned v_rd = vb + (4 * g + (i >> 2)) * 144 + (i & 3) * 8;         // transposing read: (key 4 g + (i >> 2), d 4 (i & 3) ..)  (+ 32 db)
+  // the six 16-byte pieces a lane loads of unit u (zeros beyond the last frame / the last unit); the NEXT unit's pieces are requested before
+  // this unit's are used: two units of loads in flight per wave
+  const bool rowok = i < frames;
+  auto fetch = [&](long u, uint4 (&r)[6], long& orow, int& oh) {
+#pragma unroll
+    for (int c = 0; c < 6; ++c) r[c] = make_uint4(0, 0, 0, 0);
+    orow = 0; oh = 0;
+    if (u >= total_units) return;
+    const int h = (int)(u % heads);
+    const long bp = u / heads;
+    const int pix = (int)(bp % hw), b = (int)(bp / hw);
+    orow = ((long)b * frames + i) * hw + pix; oh = h;
+    if (rowok) {
+      const char* rp = qkv + (orow * ldqkv + h * 64 + g * 8) * 2;     // head dimensions 8 g .. (k-step 0) and 32 + 8 g .. (k-step 1): 64 contiguous bytes per instruction and row
+      r[0] = *(const uint4*)rp; r[1] = *(const uint4*)(rp + 64);
+      r[2] = *(const uint4*)(rp + (long)C * 2); r[3] = *(const uint4*)(rp + (long)C * 2 + 64);
+      r[4] = *(const uint4*)(rp + (long)C * 4); r[5] = *(const uint4*)(rp + (long)C * 4 + 64);
+    }
+  };
+  const long stride = (long)gridDim.x * 4;
+  uint4 cur[6], nxt[6];
+  long orow = 0, nrow = 0;
+  int h = 0, nh = 0;
+  long u = (long)blockIdx.x * 4 + wv;
+  fetch(u, cur, orow, h);
+  for (; u < total_units; u += stride) {
+    fetch(u + stride, nxt, nrow, nh);
+    const uint4 q0 = cur[0], q1 = cur[1], k0 = cur[2], k1 = cur[3], v0 = cur[4], v1 = cur[5];
+    f32x4v sacc = {0.f, 0.f, 0.f, 0.f};
+    sacc = Cvt<Tag>::mfma16(k0, q0, sacc);
+    sacc = Cvt<Tag>::mfma16(k1, q1, sacc);
+    // the previous unit's transposing reads are done (their results fed MFMAs already): this wave's V tile may be overwritten
+    *(uint4*)(vbuf[wv] + i * 144 + g * 16) = v0;              // V row i (zeros beyond the last frame), head dimensions 8 g .. and 32 + 8 g ..
+    *(uint4*)(vbuf[wv] + i * 144 + 64 + g * 16) = v1;
+    float sc[4];
+    float mx = -INFINITY;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) { sc[r] = (4 * g + r) < frames ? sacc[r] * scale_log2e : -INFINITY; mx = fmaxf(mx, sc[r]); }
+    mx = fmaxf(mx, __shfl_xor(mx, 16));
+    mx = fmaxf(mx, __shfl_xor(mx, 32));
+    float pr[4], sum = 0.f;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) { pr[r] = fast_exp2(sc[r] - mx); sum += pr[r]; }
+    sum += __shfl_xor(sum, 16);
+    sum += __shfl_xor(sum, 32);
+    const float inv = 1.0f / sum;
+    const uint4 pb = make_uint4(pack2<Tag>(pr[0], pr[1]), pack2<Tag>(pr[2], pr[3]), 0u, 0u);
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");                      // this wave's V tile is in LDS (one wave per tile: no barrier)
+    const raw_u32x2_t t0 = lds_read8_tr_off<0>(v_rd), t1 = lds_read8_tr_off<32>(v_rd), t2 = lds_read8_tr_off<64>(v_rd), t3 = lds_read8_tr_off<96>(v_rd);
+    lds_wait<0>();
+    const f32x4v z = {0.f, 0.f, 0.f, 0.f};
+    f32x4v o[4];
+    o[0] = Cvt<Tag>::mfma16(make_uint4(t0.x, t0.y, 0u, 0u), pb, z);
+    o[1] = Cvt<Tag>::mfma16(make_uint4(t1.x, t1.y, 0u, 0u), pb, z);
+    o[2] = Cvt<Tag>::mfma16(make_uint4(t2.x, t2.y, 0u, 0u), pb, z);
+    o[3] = Cvt<Tag>::mfma16(make_uint4(t3.x, t3.y, 0u, 0u), pb, z);
+    // lane: query frame i, head dimensions 16 db + 4 g + {0..3}: four 8-byte stores, the four lane groups make 32 contiguous bytes each
+    if (rowok) {
+      char* op = out + (orow * ldo + h * 64 + 4 * g) * 2;
+#pragma unroll
+      for (int db = 0; db < 4; ++db)
+        *(uint2*)(op + db * 32) = make_uint2(pack2<Tag>(o[db][0] * inv, o[db][1] * inv), pack2<Tag>(o[db][2] * inv, o[db][3] * inv));
+    }
+#pragma unroll
+    for (int c = 0; c < 6; ++c) cur[c] = nxt[c];
+    orow = nrow; h = nh;
+  }
+}
+
 template <typename Tag, int D, int LPU>
 void launch_tattn(const void* qkv, long ldqkv, void* out, long ldo, int batch, int frames, int hw, int heads, hipStream_t st) {
   constexpr int UPB = 128 / LPU;
@@ -978,6 +1064,17 @@ void launch_tattn(const void* qkv, long ldqkv, void* out, long ldo, int batch, i
   tt_lds_opt_in((const void*)tattn_kernel<Tag, D, LPU>, (int)lds, &attr_done);
   const long units = (long)batch * hw * heads;
   const float sl2 = 1.4426950408889634f / sqrtf((float)D);
+  if constexpr (D == 64 && Elem<Tag>::ES == 2 && LPU == 16) {
+    static int mfma = -1;                                    // TT_TATTN_MFMA=0: the per-lane kernel (A/B)
+    if (mfma < 0) { const char* e = getenv("TT_TATTN_MFMA"); mfma = e ? atoi(e) : 1; }
+    if (mfma) {
+      long blocks = (units + 3) / 4;
+      if (blocks > 256 * 8) blocks = 256 * 8;                // 8 blocks of 4 waves per CU, grid-stride over the units
+      hipLaunchKernelGGL((tattn_mfma_kernel<Tag>), dim3((unsigned)blocks), dim3(256), 0, st, (const char*)qkv, ldqkv, (char*)out, ldo, batch, frames, hw,
+                         heads, sl2, units);
+      return;
+    }
+  }
   hipLaunchKernelGGL((tattn_kernel<Tag, D, LPU>), dim3((unsigned)((units + UPB - 1) / UPB)), dim3(128), lds, st,
                      (const char*)qkv, ldqkv, (char*)out, ldo, batch, frames, hw, heads, sl2);
 }

@@ -49,6 +49,10 @@ template <> struct Cvt<bf16_tag> {
   static __device__ __forceinline__ unsigned short from_f32(float f) {  // round-to-nearest-even (v_cvt_pk_bf16_f32)
     return __builtin_bit_cast(unsigned short, (__bf16)f);
   }
+  typedef float f32x4m_t __attribute__((ext_vector_type(4)));
+  static __device__ __forceinline__ f32x4m_t mfma16(uint4 a, uint4 b, f32x4m_t c) {      // 16 x 16 x 32
+    return __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_t, a), __builtin_bit_cast(bf16x8_t, b), c, 0, 0, 0);
+  }
   static __device__ __forceinline__ f32x16_t mfma32(uint4 a, uint4 b, f32x16_t c) {
     return __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8_t, a), __builtin_bit_cast(bf16x8_t, b), c, 0, 0, 0);
   }
@@ -56,6 +60,10 @@ template <> struct Cvt<bf16_tag> {
 template <> struct Cvt<f16_tag> {
   static __device__ __forceinline__ float to_f32(unsigned short b) { return (float)__builtin_bit_cast(_Float16, b); }
   static __device__ __forceinline__ unsigned short from_f32(float f) { return __builtin_bit_cast(unsigned short, (_Float16)f); }
+  typedef float f32x4m_t __attribute__((ext_vector_type(4)));
+  static __device__ __forceinline__ f32x4m_t mfma16(uint4 a, uint4 b, f32x4m_t c) {
+    return __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8_t, a), __builtin_bit_cast(f16x8_t, b), c, 0, 0, 0);
+  }
   static __device__ __forceinline__ f32x16_t mfma32(uint4 a, uint4 b, f32x16_t c) {
     return __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8_t, a), __builtin_bit_cast(f16x8_t, b), c, 0, 0, 0);
   }
