@@ -164,6 +164,15 @@ int tt_gemm_set_streaming_square(int32_t on);
  *   2  the 256 x 320 kernel only;    3  the 128 x 320 variant for every gather mode (its linear / temporal-conv / LayerNorm paths);
  *   4  as 1 without the split-K route. */
 int tt_gemm_set_big_tile(int32_t on);
+/* ABI 11 (round 6).  How TT_F32 launches of tt_gemm form their products (process-wide; also TT_F32_SPLIT=0|1 in the environment):
+ *   0  (default) exact-fp32 MFMA, v_mfma_f32_32x32x2_f32: bitwise an fmaf chain in k order, 157 TFLOP/s peak;
+ *   1  "split16": every fp32 operand x is split on the fly into two fp16 parts on different binary scales, h = fp16(x 2^-8) and
+ *      l = fp16((x - 2^8 h) 2^3), and a b ~ 2^16 a_h b_h + 2^5 (a_h b_l + a_l b_h) runs as three v_mfma_f32_32x32x16_f16 into two fp32
+ *      accumulators -- max(2^-22 |x|, 2^-28) per operand, operands up to |x| < 2^24 (beyond that the hi part overflows to inf),
+ *      3 x 8 passes per 32 x 32 x 16 block instead of 8 x 16.  Storage, epilogues,
+ *      LayerNorm statistics and accumulation stay fp32; the mode meets the north-star tolerance (rtol 1e-3 / atol 1e-4 against the
+ *      reference's CPU fp32 forward, svd/unet_spatio_temporal_condition.py:363-536) at about a third of the exact mode's step time. */
+int tt_gemm_set_f32_split(int32_t on);
 
 /* ------------------------------------------------------------------------------------------------
  * tt_conv3x3: Conv2d 3x3 / stride 1 / pad 1 with the GroupNorm (+SiLU) of its INPUT fused in -- the ResnetBlock2D convs

@@ -26,7 +26,7 @@ def test_header_and_binding_agree(lib):
 
 
 def test_version_and_arch(lib):
-    assert lib.tt_abi_version() == 10
+    assert lib.tt_abi_version() == 11
     assert lib.tt_target_arch() == b"gfx950"
 
 
@@ -192,3 +192,36 @@ def test_gemm_dispatch_rules_of_the_split_k_big_tile_route(lib):
     finally:
         lib.tt_gemm_set_big_tile(1)
     assert plan(3136, 1280, 1280, **conv(8, 14))[0] == split(2)
+
+
+def test_integration_md_stub_matches_the_header(lib):
+    """INTEGRATION.md section 4 shows the ctypes stub a maintainer of the reference would paste.  It is evaluated here as it stands
+    in the document: its TtAttnArgs must have the C compiler's sizeof(TtAttnArgs) and the tested binding's field names / offsets
+    (a stub that stops short of the struct's last field hands the library a struct it reads out of bounds), and the ABI number the
+    document quotes must be the library's."""
+    import ctypes
+    import subprocess
+    import tempfile
+    text = open(os.path.join(REPO, "INTEGRATION.md")).read()
+    blocks = [b for b in re.findall(r"```python\n(.*?)```", text, flags=re.S) if "class TtAttnArgs" in b]
+    assert len(blocks) == 1, "INTEGRATION.md must hold exactly one TtAttnArgs stub"
+    ns = {}
+    cwd = os.getcwd()
+    os.chdir(REPO)                                   # the stub loads the library by its path relative to the repository root
+    try:
+        exec(compile(blocks[0], "INTEGRATION.md:stub", "exec"), ns)
+    finally:
+        os.chdir(cwd)
+    stub = ns["TtAttnArgs"]
+    src = '#include <stdio.h>\n#include "ttvdm.h"\nint main(){printf("%zu\\n", sizeof(TtAttnArgs));return 0;}\n'
+    with tempfile.TemporaryDirectory() as d:
+        c = os.path.join(d, "s.c")
+        open(c, "w").write(src)
+        exe = os.path.join(d, "s")
+        subprocess.check_call(["gcc", "-I", os.path.join(REPO, "include"), c, "-o", exe])
+        want = int(subprocess.check_output([exe]))
+    assert ctypes.sizeof(stub) == want, (ctypes.sizeof(stub), want)
+    layout = lambda s: [(n, getattr(s, n).offset, getattr(s, n).size) for n, _ in s._fields_]
+    assert layout(stub) == layout(_lib.TtAttnArgs)
+    quoted = re.findall(r"`tt_abi_version\(\)` = (\d+)", text)
+    assert quoted and all(int(q) == lib.tt_abi_version() for q in quoted), (quoted, lib.tt_abi_version())

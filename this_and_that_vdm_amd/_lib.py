@@ -74,6 +74,7 @@ SIGNATURES = {
     "tt_gemm": (C.c_int, [C.POINTER(TtGemmArgs), _vp]),
     "tt_gemm_set_streaming_square": (C.c_int, [C.c_int32]),
     "tt_gemm_set_big_tile": (C.c_int, [C.c_int32]),
+    "tt_gemm_set_f32_split": (C.c_int, [C.c_int32]),
     "tt_gemm_plan": (C.c_int, [C.POINTER(TtGemmArgs), C.POINTER(C.c_int32)]),
     "tt_gemm_set_tile_override": (C.c_int, [_i32]),
     "tt_gemm_ws_bytes": (_sz, [C.POINTER(TtGemmArgs)]),
@@ -133,7 +134,7 @@ def load():
     for name, (res, args) in SIGNATURES.items():
         fn = getattr(lib, name)          # AttributeError here == ABI mismatch with include/ttvdm.h
         fn.restype, fn.argtypes = res, args
-    if lib.tt_abi_version() != 10:
+    if lib.tt_abi_version() != 11:
         raise RuntimeError("libttvdm.so ABI version mismatch")
     _lib = lib
     return lib

@@ -202,6 +202,14 @@ bool pp_ok(const TtGemmArgs* a) {
 // fills most of a round of 256 CUs with 256-row tiles (the finest UNet level: 50176 rows = 196 tiles): Linear (one or two sources,
 // optional LayerNorm fold of the A rows), conv3x3 stride 1 and the temporal conv, with bias / scale / row vector (groups of >= 32
 // rows) / residual / AlphaBlender epilogues.  TT_GEMM_W320=0 keeps them on the tiled kernels (A/B).
+// TT_F32 products: 0 = exact-fp32 MFMA (v_mfma_f32_32x32x2_f32, 157 TFLOP/s peak), 1 = "split16": every fp32 operand split on the fly into
+// fp16 hi + lo, three 16-bit MFMAs per product block (gemm_kernel.h, `mma`): ~2^-21 relative per product at 3 / 16 of the issue time.
+static int g_f32_split = -1;
+extern "C" int tt_gemm_set_f32_split(int32_t on) { g_f32_split = on ? 1 : 0; return TT_OK; }
+static int f32_split() {
+  if (g_f32_split < 0) { const char* e = getenv("TT_F32_SPLIT"); g_f32_split = e && atoi(e) ? 1 : 0; }
+  return g_f32_split;
+}
 static int g_w320 = -1;
 extern "C" int tt_gemm_set_big_tile(int32_t on) {
   // internal: bit 0 the 256 x 320 kernel, bit 1 its 128 x 320 variant, bit 2: that one for conv3x3 only, bit 3: its split-K route
@@ -361,6 +369,7 @@ extern "C" int32_t tt_gemm_stats_rows(const TtGemmArgs* a) {
   if (a->blend && !(a->blend == a->residual && a->ld_blend == a->ld_res)) return 0;
   if (a->rowvec && a->rowvec_rows < 32 && !(a->rowvec_rows == 1 && a->rowvec_mod == 2)) return 0;
   if (cfg[0] > 128 && cfg[1] != 320 && a->residual) return 0;         // 256-row tiles of the tiled template read the residual in-pass
+  if (a->dtype == TT_F32 && f32_split() && a->residual) return 0;      // ... and so do the split-fp16 product variants on every tile shape
   if (cfg[1] == 320 || cfg[3] == 0) {                                  // the big-tile kernels: whole tiles; the 128-row one also the 64 rows of a wave row
     if (a->m % cfg[0]) return 0;
     return (cfg[0] == 128 && seg > 0 && seg % 128 && seg % 64 == 0) ? 64 : cfg[0];
@@ -437,6 +446,7 @@ extern "C" int tt_gemm(const TtGemmArgs* a, tt_stream_t stream) {
   p.out = (char*)a->out; p.ldo = a->ldo; p.out_f32 = a->dtype == TT_F32 ? 0 : a->out_f32;   // TT_F32 stores fp32 anyway
   p.out_col_hw = a->out_col_hw; p.out_col_hwp = a->out_col_hwp;
   p.ln_fold = a->ln_fold; p.ln_eps = a->ln_eps; p.out_fp8 = a->out_fp8; p.stats = a->stats_out; p.stat_rows = a->gn_out ? a->stats_seg : (a->stats_out ? tt_gemm_stats_rows(a) : 0);
+  p.f32_split = a->dtype == TT_F32 ? f32_split() : 0;
   p.gn_out = (char*)a->gn_out; p.ld_gn = a->ld_gn; p.gn_gamma = a->gn_gamma; p.gn_beta = a->gn_beta; p.gn_eps = a->gn_eps; p.gn_silu = a->gn_silu;
   if (p.mode == 1) {
     if (p.nimg <= 0 || p.hin <= 0 || p.win <= 0 || p.hout <= 0 || p.wout <= 0 || p.stride < 1)

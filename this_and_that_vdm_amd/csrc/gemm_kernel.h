@@ -54,6 +54,7 @@ struct GemmP {
   int stat_rows;                    // rows per statistics tile (tt_gemm_stats_rows); with gn_out: rows per GroupNorm segment
   char* gn_out; long ld_gn;         // != NULL: the split-K reduction also writes act(GroupNorm(out)) (TtGemmArgs.gn_out)
   const float* gn_gamma; const float* gn_beta; float gn_eps; int gn_silu;
+  int f32_split;                    // TT_F32 only: products on the 16-bit matrix pipe as three split-fp16 terms (tt_gemm_set_f32_split)
   // launch-uniform divisors of the tiled template as multiply-shift pairs (fill_fastdivs, called by launch_cfg)
   FastDiv fd_splitk, fd_per_group, fd_group_m, fd_last_rows, fd_per_tap, fd_hwo, fd_wout, fd_hw, fd_frames, fd_rv_rows, fd_rv_mod;
 };
@@ -288,10 +289,13 @@ constexpr int gemm_min_waves(int BM, int BN, int CPR, int NST, int NT) {
 // products per dword next to the MFMAs -- no statistics pass, no extra memory traffic, no normalised copy of the tensor.
 // One-pass variance (E[x^2] - E[x]^2, fp32 sums): relative error ~6e-8 * (1 + mean^2 / var), i.e. fine for |row mean| <= ~50 sigma
 // (tests/test_ops_gpu.py::test_gemm_fused_layernorm_rows_with_large_row_means); far beyond that use tt_layernorm + a plain GEMM.
-template <typename Tag, int BM, int BN, int BK, int NST, int WGM, int WGN, int KMODE>
+template <typename Tag, int BM, int BN, int BK, int NST, int WGM, int WGN, int KMODE_>
 __global__ __launch_bounds__(64 * WGM * WGN, gemm_min_waves(BM, BN, BK / Elem<Tag>::EPC, NST, 64 * WGM * WGN))
 void gemm_kernel(const GemmP p) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
+  constexpr bool SPLIT = KMODE_ >= 8;                  // f32_tag only: KMODE + 8 = the same kernel with split-fp16 products (see `mma`)
+  constexpr int KMODE = SPLIT ? KMODE_ - 8 : KMODE_;
+  static_assert(!SPLIT || std::is_same<Tag, f32_tag>::value, "split products are a TT_F32 mode");
   constexpr int MODE = KMODE >= 3 ? 0 : KMODE;         // gather mode
   constexpr int LN = KMODE >= 3 ? KMODE - 2 : 0;       // 0 none, 1 statistics of A rows, 2 of W rows
   TL(0);
@@ -512,7 +516,38 @@ void gemm_kernel(const GemmP p) {
       ln_c[i] = ok ? *(const float*)((LN == 1 ? p.a0 : p.w) + (long)row * (LN == 1 ? p.lda0 : p.ldw) * 4) : 0.f;
     }
   }
-  auto mma = [&](const raw_u32x4_t (&af)[FM], const raw_u32x4_t (&bf)[FN]) {
+  // TT_F32 "split16" (round 6): fp32-class products at the 16-bit matrix rate.  Every fp32 operand x is split on the fly into two fp16
+  // parts on DIFFERENT binary scales,
+  //     h = fp16(x 2^-8),   l = fp16((x - 2^8 h) 2^3)          x = 2^8 h + 2^-3 l  up to  max(2^-22 |x|, 2^-28)
+  // so that |x| up to 2^24 fits (an unscaled fp16 hi part overflows at 65504: proj_in of the tiny test model sees 1.8e5, and inf x 0
+  // is NaN) while the lo part -- which also repairs the denormal quantisation of h for |x| < 2^-6 -- stays a normal fp16 number for
+  // every x whose h is normal (fp16 denormals are KEPT by the gfx950 MFMA: tools/mfma_split_probe.hip).  Then
+  //     a b = 2^16 a_h b_h + 2^5 (a_h b_l + a_l b_h) + 2^-6 a_l b_l (dropped: 2^-22 of the product)
+  // runs as three v_mfma_f32_32x32x16_f16 per product block into TWO fp32 accumulators (the hi x hi sum and the cross-term sum carry
+  // different scales), combined once after the K loop.  One 16-deep MFMA needs 8 k-values per lane: two consecutive fragment sets
+  // (4 fp32 each) -- the loops below consume the sets in pairs already, so the even set is split and parked in registers (phase 0)
+  // and the odd set triggers the MFMAs (phase 1).  Both operands use the same (lane half, slot) -> k map, which is all the instruction
+  // needs.  Per 32 x 32 x 16 block: 3 x 8 passes against 8 x 16 passes of v_mfma_f32_32x32x2_f32.
+  uint2 sp_ah[SPLIT ? FM : 1], sp_al[SPLIT ? FM : 1], sp_bh[SPLIT ? FN : 1], sp_bl[SPLIT ? FN : 1];
+  f32x16_t accx[SPLIT ? FM : 1][SPLIT ? FN : 1];        // cross terms a_h b_l + a_l b_h
+  if constexpr (SPLIT) {
+#pragma unroll
+    for (int i = 0; i < FM; ++i)
+#pragma unroll
+      for (int j = 0; j < FN; ++j)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) accx[i][j][r] = 0.f;
+  }
+  auto split4 = [](const raw_u32x4_t& f, uint2& h, uint2& l) {
+    const f32x2_t x01 = (f32x2_t){__uint_as_float(f.x), __uint_as_float(f.y)} * 0.00390625f;      // x 2^-8
+    const f32x2_t x23 = (f32x2_t){__uint_as_float(f.z), __uint_as_float(f.w)} * 0.00390625f;
+    const f16x2_t h01 = __builtin_convertvector(x01, f16x2_t), h23 = __builtin_convertvector(x23, f16x2_t);
+    h = make_uint2(__builtin_bit_cast(unsigned, h01), __builtin_bit_cast(unsigned, h23));
+    const f32x2_t r01 = (x01 - __builtin_convertvector(h01, f32x2_t)) * 2048.0f;                  // exact residual, x 2^11
+    const f32x2_t r23 = (x23 - __builtin_convertvector(h23, f32x2_t)) * 2048.0f;
+    l = make_uint2(__builtin_bit_cast(unsigned, __builtin_convertvector(r01, f16x2_t)), __builtin_bit_cast(unsigned, __builtin_convertvector(r23, f16x2_t)));
+  };
+  auto mma = [&](const raw_u32x4_t (&af)[FM], const raw_u32x4_t (&bf)[FN], int phase) {
     if constexpr (LN == 1) {
 #pragma unroll
       for (int i = 0; i < FM; ++i) {
@@ -524,11 +559,43 @@ void gemm_kernel(const GemmP p) {
         if constexpr (LN_SHIFT) ln_stat_shifted(bf[j], ln_c[j], ln_s[j], ln_q[j]); else ln_stat<Tag>(bf[j], ln_s[j], ln_q[j]);
       }
     }
+    if constexpr (SPLIT) {
+      if (phase == 0) {                      // (constant after unrolling)
 #pragma unroll
-    for (int i = 0; i < FM; ++i)
+        for (int i = 0; i < FM; ++i) split4(af[i], sp_ah[i], sp_al[i]);
 #pragma unroll
-      for (int j = 0; j < FN; ++j)
-        acc[i][j] = Cvt<Tag>::mfma32(make_uint4(bf[j].x, bf[j].y, bf[j].z, bf[j].w), make_uint4(af[i].x, af[i].y, af[i].z, af[i].w), acc[i][j]);
+        for (int j = 0; j < FN; ++j) split4(bf[j], sp_bh[j], sp_bl[j]);
+      } else {
+        uint4 ah[FM], al[FM], bh[FN], bl[FN];
+#pragma unroll
+        for (int i = 0; i < FM; ++i) {
+          uint2 h, l;
+          split4(af[i], h, l);
+          ah[i] = make_uint4(sp_ah[i].x, sp_ah[i].y, h.x, h.y); al[i] = make_uint4(sp_al[i].x, sp_al[i].y, l.x, l.y);
+        }
+#pragma unroll
+        for (int j = 0; j < FN; ++j) {
+          uint2 h, l;
+          split4(bf[j], h, l);
+          bh[j] = make_uint4(sp_bh[j].x, sp_bh[j].y, h.x, h.y); bl[j] = make_uint4(sp_bl[j].x, sp_bl[j].y, l.x, l.y);
+        }
+#pragma unroll
+        for (int i = 0; i < FM; ++i)
+#pragma unroll
+          for (int j = 0; j < FN; ++j) {
+            accx[i][j] = Cvt<f16_tag>::mfma32(bl[j], ah[i], accx[i][j]);
+            acc[i][j] = Cvt<f16_tag>::mfma32(bh[j], ah[i], acc[i][j]);
+            accx[i][j] = Cvt<f16_tag>::mfma32(bh[j], al[i], accx[i][j]);
+          }
+      }
+      __builtin_amdgcn_sched_barrier(0);     // the conversions read raw-asm fragment registers: same pinning as the statistics below
+    } else {
+#pragma unroll
+      for (int i = 0; i < FM; ++i)
+#pragma unroll
+        for (int j = 0; j < FN; ++j)
+          acc[i][j] = Cvt<Tag>::mfma32(make_uint4(bf[j].x, bf[j].y, bf[j].z, bf[j].w), make_uint4(af[i].x, af[i].y, af[i].z, af[i].w), acc[i][j]);
+    }
     // The fragment registers are written by raw asm ds_reads whose data lands later (cdna guide 5.7 item 1).  If the
     // scheduler sinks the statistics VALU below the NEXT raw read of the same fragment set, the two values are live at once,
     // the new read gets other registers and a v_mov copies them back at the loop edge -- before the data has landed
@@ -542,7 +609,7 @@ void gemm_kernel(const GemmP p) {
   // (The AlphaBlender source is usually the residual tensor itself -- temporal ResBlock -- and then shares the
   // preloaded value; a distinct blend tensor is read in-pass.)
   constexpr int NCH = (FN + 1) / 2;                    // 64-column chunks per fragment row
-  constexpr bool EARLY_RES = BM <= 128;
+  constexpr bool EARLY_RES = BM <= 128 && !SPLIT;     // (the split variant needs the 64 registers for its operand halves)
   quad_t resv[EARLY_RES ? FM : 1][EARLY_RES ? NCH : 1][8];   // 256-row tiles read the residual inside the passes
   const bool direct = (p.out_col_hw > 0 || p.out_f32) && p.splitk == 1;   // rare layouts keep the simple per-fragment path
   const bool blend_is_res = p.blend && p.blend == p.residual && p.ld_blend == p.ld_res;
@@ -606,7 +673,7 @@ void gemm_kernel(const GemmP p) {
         } else {
           lds_wait<0>();
         }
-        mma(af[ks & 1], bf[ks & 1]);
+        mma(af[ks & 1], bf[ks & 1], ks & 1);
       }
     }
   } else {
@@ -635,7 +702,7 @@ void gemm_kernel(const GemmP p) {
       for (int ks = 0; ks < KS; ks += 2) {
         read_frags(sa, ks + 1, afB, bfB);
         lds_wait<NF>();                       // set A (issued before set B) has landed
-        mma(afA, bfA);
+        mma(afA, bfA, 0);
         if (ks + 2 < KS) {
           read_frags(sa, ks + 2, afA, bfA);
           lds_wait<NF>();                     // set B has landed
@@ -650,7 +717,7 @@ void gemm_kernel(const GemmP p) {
         } else {
           lds_wait<0>();
         }
-        mma(afB, bfB);
+        mma(afB, bfB, 1);
       }
       slot = nslot;
       fill = fill + 1 == NST ? 0 : fill + 1;
@@ -659,6 +726,14 @@ void gemm_kernel(const GemmP p) {
     tile(KT - 1, std::true_type{});
   }
 
+  if constexpr (SPLIT) {                               // 2^16 (hi x hi) + 2^5 (cross terms)
+#pragma unroll
+    for (int i = 0; i < FM; ++i)
+#pragma unroll
+      for (int j = 0; j < FN; ++j)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[i][j][r] = fmaf(accx[i][j][r], 32.0f, acc[i][j][r] * 65536.0f);
+  }
   // ---- fused LayerNorm: 1/sigma of the operand rows from the sums gathered beside the MFMAs (the two lane halves hold the
   // even / odd chunks of a row).  Rows: scale the accumulators now (lane <-> row l31).  Columns: the lane that owns W row
   // l31 of fragment j publishes 1/sigma of output column j*32 + l31 in a wave-private LDS array behind the ring; the
@@ -1290,9 +1365,9 @@ template <typename Tag, int BM, int BN, int BK, int NST, int WGM, int WGN, int M
 void launch_mode(const GemmP& p, hipStream_t st) {
   constexpr int NT_ = 64 * WGM * WGN, CPR_ = BK / Elem<Tag>::EPC;
   constexpr size_t lds = (size_t)NST * (((BM * CPR_ + NT_ - 1) / NT_) + ((BN * CPR_ + NT_ - 1) / NT_)) * NT_ * 16
-                         + (MODE == 4 ? WGM * WGN * 1024 : 0);          // + the per-wave column-scale arrays
+                         + ((MODE & 7) == 4 ? WGM * WGN * 1024 : 0);    // + the per-wave column-scale arrays  (MODE + 8: split-fp16 products, TT_F32)
   static_assert(lds + (size_t)WGM * WGN * 2 * (BN / WGN) * sizeof(float) <= 160 * 1024, "LDS ring (+ the statistics staging rows) exceeds 160 KiB");
-  static_assert(MODE != 4 || BN / WGN <= 256, "column-scale array: 1 KiB per wave");
+  static_assert((MODE & 7) != 4 || BN / WGN <= 256, "column-scale array: 1 KiB per wave");
   constexpr size_t stat_lds = (size_t)WGM * WGN * 2 * (BN / WGN) * sizeof(float);        // per wave: sum and sum-of-squares rows of its columns
   static unsigned long long attr_done = 0;     // per kernel instance, one bit per device (see tt_lds_opt_in)
   tt_lds_opt_in((const void*)gemm_kernel<Tag, BM, BN, BK, NST, WGM, WGN, MODE>, (int)(lds + stat_lds), &attr_done);
@@ -1339,6 +1414,18 @@ void launch_cfg(GemmP& p, hipStream_t st) {
   p.nk0 = ceil_div(p.k0, BK); p.nk1 = p.k1 ? ceil_div(p.k1, BK) : 0;
   p.kt_total = p.taps * (p.nk0 + p.nk1);
   fill_fastdivs(p);
+  if constexpr (std::is_same<Tag, f32_tag>::value) {
+    if (p.f32_split) {                       // tt_gemm_set_f32_split(1): the split-fp16 product variants (KMODE + 8)
+      if (LNOK && p.ln_fold == 1) { launch_mode<Tag, BM, BN, BK, NST, WGM, WGN, 11>(p, st); return; }
+      if (LNOK && p.ln_fold == 2) { launch_mode<Tag, BM, BN, BK, NST, WGM, WGN, 12>(p, st); return; }
+      switch (p.mode) {
+        case 0: launch_mode<Tag, BM, BN, BK, NST, WGM, WGN, 8>(p, st); break;
+        case 1: launch_mode<Tag, BM, BN, BK, NST, WGM, WGN, 9>(p, st); break;
+        default: launch_mode<Tag, BM, BN, BK, NST, WGM, WGN, 10>(p, st); break;
+      }
+      return;
+    }
+  }
   if constexpr (LNOK) {
     if (p.ln_fold == 1) { launch_mode<Tag, BM, BN, BK, NST, WGM, WGN, 3>(p, st); return; }
     if (p.ln_fold == 2) { launch_mode<Tag, BM, BN, BK, NST, WGM, WGN, 4>(p, st); return; }

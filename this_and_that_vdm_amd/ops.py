@@ -61,6 +61,23 @@ def _code(dt: torch.dtype) -> int:
     raise RuntimeError(f"libttvdm activations/weights must be bfloat16, float16 or float32, got {dt}")
 
 
+# TT_F32 products: exact-fp32 MFMA (default) or "split16" -- fp32 operands split on the fly into fp16 hi + lo, three 16-bit MFMAs per
+# product block (tt_gemm_set_f32_split, include/ttvdm.h): the mode that meets the north-star tolerance at about a third of the time.
+_F32_SPLIT = os.environ.get("TT_F32_SPLIT", "0") not in ("", "0")
+
+
+def set_f32_split(on: bool) -> None:
+    """Process-wide: TT_F32 launches of gemm() use split-fp16 products (True) or the exact-fp32 MFMA (False).  Part of DenoiseLoop's
+    graph key, so a captured step is never replayed in the other mode."""
+    global _F32_SPLIT
+    check(_lib.load().tt_gemm_set_f32_split(int(bool(on))), "tt_gemm_set_f32_split")
+    _F32_SPLIT = bool(on)
+
+
+def f32_split() -> bool:
+    return _F32_SPLIT
+
+
 _TAG = {TT_BF16: "bf16_tag", TT_F16: "f16_tag", TT_F32: "f32_tag"}
 FP8 = torch.float8_e4m3fn          # OCP e4m3 (gfx950's fp8; not MI300's fnuz)
 
@@ -180,7 +197,8 @@ def gemm(a0: torch.Tensor, w: torch.Tensor, *, a1: Optional[torch.Tensor] = None
         elif cfg[0] == 32 and cfg[1] == 320:        # the opt-in streaming kernel for the 320 x 320 linears
             kname = f"sq320_kernel<{tag}, {'true' if residual is not None else 'false'}>"
         else:
-            kname = f"gemm_kernel<{tag}, {', '.join(str(v) for v in cfg[:6])}, {mode if not ln_fold else 2 + ln_fold}>"
+            kmode = (mode if not ln_fold else 2 + ln_fold) + (8 if (g.dtype == TT_F32 and _F32_SPLIT) else 0)     # + 8: split-fp16 products
+            kname = f"gemm_kernel<{tag}, {', '.join(str(v) for v in cfg[:6])}, {kmode}>"
         _prof_end(ev, kname, 2.0 * g.m * n * taps * (g.k0 + g.k1),
                   shape=(mode, g.m, n, taps * (g.k0 + g.k1), int(geglu), int(residual is not None)))
     return out

@@ -70,7 +70,8 @@ class DenoiseLoop:
         # of the key, so load_state_dict / .to() / in-place updates between requests drop the stale graphs
         packs = self._pack_state()
         key = (b, f, h, w, dtype, self.controlnet is not None, tuple(encoder_hidden_states.shape), len(timesteps),
-               guidance_scale is not None, self.image_guidance_scale, packs)   # the image scale is baked into the graph
+               guidance_scale is not None, self.image_guidance_scale, packs,   # the image scale is baked into the graph
+               ops.f32_split())                                                # ... and so is the TT_F32 product mode (kernel variants)
         if key != self._key:                    # new shapes or new weights: new static buffers, new graph
             self._graph, self._graph_off, self._key, self._static = None, None, key, {}
         self._packs = packs                     # what the FiLM table, the context projections and the graphs below were built from
