@@ -126,6 +126,13 @@ typedef struct TtGemmArgs {
   void* gn_out; int64_t ld_gn;
   const float* gn_gamma; const float* gn_beta;
   float gn_eps; int32_t gn_silu;
+  /* ABI 11.  TT_F32 with tt_gemm_set_f32_split(1) only: an operand that is a constant of the request (packed weights) may be handed over
+   * PRE-SPLIT, so the kernel does not convert it again in every launch: bit 0 = a0 / a1, bit 1 = w.  A pre-split matrix has the shape,
+   * strides and element size of the fp32 matrix it replaces; every aligned group of 4 consecutive k-elements (16 bytes) holds the eight
+   * fp16 values  h0 h1 h2 h3 l0 l1 l2 l3  with  h = fp16(x 2^-8), l = fp16((x - 2^8 h) 2^3)  of its four fp32 values
+   * (this_and_that_vdm_amd/packing.py:presplit_f32).  Not together with the LayerNorm statistics of that operand (ln_fold 1 with
+   * bit 0, ln_fold 2 with bit 1).  0 = plain fp32 operands. */
+  int32_t presplit;
 } TtGemmArgs;
 int tt_gemm(const TtGemmArgs* args, tt_stream_t stream);
 /* 1 if tt_gemm serves `args` with gn_out (a split-K plan, 16-bit storage, stats_seg rows per segment dividing m and short enough for one

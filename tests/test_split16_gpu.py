@@ -202,3 +202,52 @@ def test_split16_switch_is_part_of_the_graph_key(ops):
     assert not torch.equal(split, exact)
     contrib = lambda z: z - args["latents"].cuda().reshape(z.shape) * float(sched.sigmas[1] / sched.sigmas[0])
     torch.testing.assert_close(contrib(split), contrib(exact), rtol=1e-3, atol=1e-4)
+
+
+@pytest.mark.parametrize("m,n,k", [(1000, 320, 640), (2048, 2048, 320), (300, 72, 40)])
+def test_split16_presplit_operands_are_bit_identical_to_on_the_fly_conversion(ops, m, n, k):
+    """TtGemmArgs.presplit: a packed weight handed over as fp16 (h, l) pairs (packing.presplit_f32, done once per pack) gives the
+    bits the kernel's own conversion gives -- as the W operand (every Linear / conv) and as the A operand (the swapped V^T projection,
+    whose LayerNorm statistics come from the other operand), also through a row slice of the pre-split matrix."""
+    from this_and_that_vdm_amd.packing import PreSplitF32, fold_layernorm, presplit_f32
+    a, w, bias = f32(m, k, seed=1, scale=3.0), f32(n, k, seed=2, scale=k ** -0.5), f32(n, seed=3)
+    wp = presplit_f32(w.cuda())
+    assert isinstance(wp, PreSplitF32) and wp.shape == w.shape and wp.dtype == torch.float32 and isinstance(wp[: n // 2], PreSplitF32)
+    ref = ops.gemm(a.cuda(), w.cuda(), bias=bias.cuda())
+    assert torch.equal(ops.gemm(a.cuda(), wp, bias=bias.cuda()), ref)
+    half = (n // 2) // 4 * 4
+    assert torch.equal(ops.gemm(a.cuda(), wp[:half], bias=bias[:half].cuda()), ref[:, :half])
+    if k % 8 == 0 and m % 4 == 0:
+        g, be = f32(k, seed=4, scale=0.2) + 1, f32(k, seed=5, scale=0.3)
+        wf, _ = fold_layernorm(w, None, g, be)
+        swapped = ops.gemm(wf.cuda(), a.cuda(), ln_fold=2, ln_eps=1e-5)
+        assert torch.equal(ops.gemm(presplit_f32(wf.cuda()), a.cuda(), ln_fold=2, ln_eps=1e-5), swapped)
+    with pytest.raises(RuntimeError, match="pre-split"):                       # the statistics cannot come from a pre-split operand
+        ops.gemm(a.cuda(), wp, ln_fold=2, ln_eps=1e-5)
+    ops.set_f32_split(False)
+    try:
+        with pytest.raises(RuntimeError, match="outside the split16 mode"):
+            ops.gemm(a.cuda(), wp)
+    finally:
+        ops.set_f32_split(True)
+
+
+@torch.no_grad()
+def test_split16_models_pack_their_weights_pre_split(ops):
+    """prepare() under split16 hands every packed GEMM weight over pre-split (and repacks when the mode is toggled)."""
+    from tests.parity_common import build_pair
+    from this_and_that_vdm_amd.packing import PreSplitF32
+    p_unet, p_cn, _, _ = build_pair("tiny_vgl", torch.float32, "cuda:0", True)
+    p_unet.prepare(); p_cn.prepare()
+    blk = p_unet.down_blocks[0]
+    res, tfm = blk.resnets[0].spatial_res_block, blk.attentions[0]
+    for t in (res.w1, res.w2, tfm.w_in, tfm.transformer_blocks[0].wqkv, tfm.transformer_blocks[0].wqk, tfm.transformer_blocks[0].wv,
+              tfm.transformer_blocks[0].ff.wg, tfm.transformer_blocks[0].q2.w, p_unet._w_in, p_unet._k_w, p_cn._zero[0][0], p_cn._zero_mid[0]):
+        assert isinstance(t, PreSplitF32), type(t)
+    gen = p_unet._pack_gen
+    ops.set_f32_split(False)
+    try:
+        p_unet.prepare()
+        assert p_unet._pack_gen == gen + 1 and not isinstance(p_unet.down_blocks[0].resnets[0].spatial_res_block.w1, PreSplitF32)
+    finally:
+        ops.set_f32_split(True)

@@ -33,6 +33,7 @@ class TtGemmArgs(C.Structure):
         ("stats_seg", C.c_int32),           # ... rows of the consumer's GroupNorm segment (hint for the statistics tile height)
         ("gn_out", C.c_void_p), ("ld_gn", C.c_int64), ("gn_gamma", C.c_void_p), ("gn_beta", C.c_void_p),      # ABI 9: GroupNorm in the split-K reduction
         ("gn_eps", C.c_float), ("gn_silu", C.c_int32),
+        ("presplit", C.c_int32),            # ABI 11: bit 0 a0 / a1, bit 1 w hold pre-split fp16 pairs (TT_F32 split16 mode)
     ]
 
 

@@ -142,7 +142,7 @@ Plan make_plan(int m, int n, long ktot, bool allow_split, bool wide_ok = true, b
 }
 
 constexpr TileCfg kCfgsF32[] = {{128, 128, 32, 2, 2, 2}, {64, 64, 32, 4, 2, 2}};
-int plan_f32(int m, int n) { return (long)ceil_div(m, 128) * ceil_div(n, 128) >= 256 ? 0 : 1; }
+int plan_f32(int m, int n, int min_tiles = 256) { return (long)ceil_div(m, 128) * ceil_div(n, 128) >= min_tiles ? 0 : 1; }
 
 }  // namespace
 
@@ -307,7 +307,18 @@ static void pp_split(const TtGemmArgs* a, int rows, TtGemmArgs* head, TtGemmArgs
 // tile shapes whose fused-LayerNorm variants are built (launch<Tag>() in gemm_kernel.h): the ones the planner picks
 static bool ln_capable(int cfg) { return cfg == 1 || cfg == 2 || cfg == 3 || cfg == 7 || cfg == 9 || cfg == 11 || cfg == 16; }
 static Plan plan_for(const TtGemmArgs* a) {
-  if (a->dtype == TT_F32) return Plan{plan_f32(a->m, a->n), 1};
+  if (a->dtype == TT_F32) {
+    // split16: the 64 x 64 tiles' 32 x 32 wave tiles convert two operand fragments per product block (VALU-bound, ~110 TFLOP/s against
+    // ~210 on the 128 x 128 tiles' 64 x 64 wave tiles), so the big tile is taken from 160 tiles on (3136 x 1280: 250 tiles = one round)
+    static int split_min = -1;
+    if (split_min < 0) { const char* e = getenv("TT_F32_SPLIT_MIN_TILES"); split_min = e ? atoi(e) : 160; }
+    // (256 x 128 tiles with 8 waves -- the same wave tiles, 25 % less LDS fill per flop, one workgroup per CU -- measured SLOWER:
+    // 109.3 -> 114.1 ms / step, one call; the loop is bound by the VALU conversions + MFMA issue of its two waves per SIMD, not by the fill)
+    // Other shapes of the big tile, each one gpurun call against 106-108 ms / step for this one: 128 x 128 x 16 with a 4-deep / 3-deep ring
+    // (three / two tiles in flight instead of one) 112.7 / 112.0; x 32 with a 3-deep ring (96 KiB: one workgroup per CU) 135.5; 8 waves
+    // as 4 x 2 / 2 x 4 (wave tiles 32 x 64 / 64 x 32 at a 128-register budget) 123.4 / 234.2; 128 x 64 x 32, 3-deep 127.7.
+    return Plan{plan_f32(a->m, a->n, f32_split() ? split_min : 256), 1};
+  }
   const int taps = a->mode == 1 ? 9 : (a->mode == 2 ? 3 : 1);
   const bool allow = !a->geglu && !a->ln_fold && !a->out_fp8;       // a K slice would see only part of a LayerNorm row
   const bool k128 = (a->k0 & 127) == 0 && (a->k1 & 127) == 0;
@@ -447,6 +458,13 @@ extern "C" int tt_gemm(const TtGemmArgs* a, tt_stream_t stream) {
   p.out_col_hw = a->out_col_hw; p.out_col_hwp = a->out_col_hwp;
   p.ln_fold = a->ln_fold; p.ln_eps = a->ln_eps; p.out_fp8 = a->out_fp8; p.stats = a->stats_out; p.stat_rows = a->gn_out ? a->stats_seg : (a->stats_out ? tt_gemm_stats_rows(a) : 0);
   p.f32_split = a->dtype == TT_F32 ? f32_split() : 0;
+  p.presplit = a->presplit;
+  if (a->presplit) {
+    if ((a->presplit & ~3) || a->dtype != TT_F32 || !p.f32_split)
+      TT_FAIL(TT_EINVAL, "tt_gemm: presplit operands need TT_F32 with tt_gemm_set_f32_split(1)");
+    if (((a->presplit & 1) && a->ln_fold == 1) || ((a->presplit & 2) && a->ln_fold == 2))
+      TT_FAIL(TT_EINVAL, "tt_gemm: the LayerNorm statistics cannot be taken from a pre-split operand");
+  }
   p.gn_out = (char*)a->gn_out; p.ld_gn = a->ld_gn; p.gn_gamma = a->gn_gamma; p.gn_beta = a->gn_beta; p.gn_eps = a->gn_eps; p.gn_silu = a->gn_silu;
   if (p.mode == 1) {
     if (p.nimg <= 0 || p.hin <= 0 || p.win <= 0 || p.hout <= 0 || p.wout <= 0 || p.stride < 1)

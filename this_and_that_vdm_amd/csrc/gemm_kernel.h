@@ -55,6 +55,7 @@ struct GemmP {
   char* gn_out; long ld_gn;         // != NULL: the split-K reduction also writes act(GroupNorm(out)) (TtGemmArgs.gn_out)
   const float* gn_gamma; const float* gn_beta; float gn_eps; int gn_silu;
   int f32_split;                    // TT_F32 only: products on the 16-bit matrix pipe as three split-fp16 terms (tt_gemm_set_f32_split)
+  int presplit;                     // ... bit 0: a0 / a1, bit 1: w already hold the fp16 (h, l) pairs (TtGemmArgs.presplit)
   // launch-uniform divisors of the tiled template as multiply-shift pairs (fill_fastdivs, called by launch_cfg)
   FastDiv fd_splitk, fd_per_group, fd_group_m, fd_last_rows, fd_per_tap, fd_hwo, fd_wout, fd_hw, fd_frames, fd_rv_rows, fd_rv_mod;
 };
@@ -538,15 +539,24 @@ void gemm_kernel(const GemmP p) {
 #pragma unroll
         for (int r = 0; r < 16; ++r) accx[i][j][r] = 0.f;
   }
-  auto split4 = [](const raw_u32x4_t& f, uint2& h, uint2& l) {
-    const f32x2_t x01 = (f32x2_t){__uint_as_float(f.x), __uint_as_float(f.y)} * 0.00390625f;      // x 2^-8
-    const f32x2_t x23 = (f32x2_t){__uint_as_float(f.z), __uint_as_float(f.w)} * 0.00390625f;
-    const f16x2_t h01 = __builtin_convertvector(x01, f16x2_t), h23 = __builtin_convertvector(x23, f16x2_t);
+  // conversion of one fragment set (4 fp32 values): 10 VALU -- two packed scalings, two packed conversions for h, and one
+  // v_fma_mixlo / mixhi_f16 per value for l = fp16(8 x - 2048 h): the instruction widens its fp16 operand, fuses and rounds once.
+  // An operand the caller pre-split (GemmP.presplit: packed weights) arrives as (h01, h23, l01, l23) already: no VALU at all.
+  const float kM2048 = -2048.0f;
+  auto split4 = [&](const raw_u32x4_t& f, bool pre, uint2& h, uint2& l) {
+    if (pre) { h = make_uint2(f.x, f.y); l = make_uint2(f.z, f.w); return; }
+    const f32x2_t v01 = (f32x2_t){__uint_as_float(f.x), __uint_as_float(f.y)}, v23 = (f32x2_t){__uint_as_float(f.z), __uint_as_float(f.w)};
+    const f16x2_t h01 = __builtin_convertvector(v01 * 0.00390625f, f16x2_t), h23 = __builtin_convertvector(v23 * 0.00390625f, f16x2_t);   // fp16(x 2^-8)
     h = make_uint2(__builtin_bit_cast(unsigned, h01), __builtin_bit_cast(unsigned, h23));
-    const f32x2_t r01 = (x01 - __builtin_convertvector(h01, f32x2_t)) * 2048.0f;                  // exact residual, x 2^11
-    const f32x2_t r23 = (x23 - __builtin_convertvector(h23, f32x2_t)) * 2048.0f;
-    l = make_uint2(__builtin_bit_cast(unsigned, __builtin_convertvector(r01, f16x2_t)), __builtin_bit_cast(unsigned, __builtin_convertvector(r23, f16x2_t)));
+    const f32x2_t e01 = v01 * 8.0f, e23 = v23 * 8.0f;                      // (x - 2^8 h) 2^3 = 8 x - 2048 h, exact in fp32
+    unsigned l01, l23;
+    asm("v_fma_mixlo_f16 %0, %1, %2, %3 op_sel_hi:[1,0,0]" : "=v"(l01) : "v"(h.x), "v"(kM2048), "v"(e01.x));
+    asm("v_fma_mixhi_f16 %0, %1, %2, %3 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "+v"(l01) : "v"(h.x), "v"(kM2048), "v"(e01.y));
+    asm("v_fma_mixlo_f16 %0, %1, %2, %3 op_sel_hi:[1,0,0]" : "=v"(l23) : "v"(h.y), "v"(kM2048), "v"(e23.x));
+    asm("v_fma_mixhi_f16 %0, %1, %2, %3 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "+v"(l23) : "v"(h.y), "v"(kM2048), "v"(e23.y));
+    l = make_uint2(l01, l23);
   };
+  const bool pre_a = SPLIT && (p.presplit & 1), pre_b = SPLIT && (p.presplit & 2);      // launch-uniform
   auto mma = [&](const raw_u32x4_t (&af)[FM], const raw_u32x4_t (&bf)[FN], int phase) {
     if constexpr (LN == 1) {
 #pragma unroll
@@ -562,21 +572,21 @@ void gemm_kernel(const GemmP p) {
     if constexpr (SPLIT) {
       if (phase == 0) {                      // (constant after unrolling)
 #pragma unroll
-        for (int i = 0; i < FM; ++i) split4(af[i], sp_ah[i], sp_al[i]);
+        for (int i = 0; i < FM; ++i) split4(af[i], pre_a, sp_ah[i], sp_al[i]);
 #pragma unroll
-        for (int j = 0; j < FN; ++j) split4(bf[j], sp_bh[j], sp_bl[j]);
+        for (int j = 0; j < FN; ++j) split4(bf[j], pre_b, sp_bh[j], sp_bl[j]);
       } else {
         uint4 ah[FM], al[FM], bh[FN], bl[FN];
 #pragma unroll
         for (int i = 0; i < FM; ++i) {
           uint2 h, l;
-          split4(af[i], h, l);
+          split4(af[i], pre_a, h, l);
           ah[i] = make_uint4(sp_ah[i].x, sp_ah[i].y, h.x, h.y); al[i] = make_uint4(sp_al[i].x, sp_al[i].y, l.x, l.y);
         }
 #pragma unroll
         for (int j = 0; j < FN; ++j) {
           uint2 h, l;
-          split4(bf[j], h, l);
+          split4(bf[j], pre_b, h, l);
           bh[j] = make_uint4(sp_bh[j].x, sp_bh[j].y, h.x, h.y); bl[j] = make_uint4(sp_bl[j].x, sp_bl[j].y, l.x, l.y);
         }
 #pragma unroll

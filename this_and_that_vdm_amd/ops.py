@@ -11,6 +11,7 @@ import torch
 
 from . import _lib
 from ._lib import TT_BF16, TT_F16, TT_F32, TtAttnArgs, TtConvArgs, TtGemmArgs, check
+from .packing import PreSplitF32
 
 
 # Optional launch profiler (bench.py): when set to a list, gemm()/attention() append
@@ -157,6 +158,11 @@ def gemm(a0: torch.Tensor, w: torch.Tensor, *, a1: Optional[torch.Tensor] = None
         g.out_col_hw, g.out_col_hwp = out_col_pad
     g.dtype = _code(a0.dtype)
     g.ln_fold, g.ln_eps = int(ln_fold), float(ln_eps)
+    if g.dtype == TT_F32 and _F32_SPLIT:       # operands packed as fp16 (h, l) pairs (packing.presplit_f32): no conversion in the kernel
+        g.presplit = (1 if isinstance(a0, PreSplitF32) else 0) | (2 if isinstance(w, PreSplitF32) else 0)
+    elif isinstance(a0, PreSplitF32) or isinstance(w, PreSplitF32):
+        raise RuntimeError("gemm: a pre-split operand outside the split16 mode (set_f32_split changed after the weights were packed: "
+                           "call prepare() / begin() again)")
     need = lib.tt_gemm_ws_bytes(C.byref(g))
     if need:
         ws = _workspace(need, a0.device)

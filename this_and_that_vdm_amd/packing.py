@@ -138,3 +138,26 @@ def permute_q_rows(t: torch.Tensor) -> torch.Tensor:
     idx = torch.arange(n, device=t.device)
     d = (idx & ~12) | ((idx & 4) << 1) | ((idx & 8) >> 1)
     return t[d].contiguous()
+
+
+class PreSplitF32(torch.Tensor):
+    """An fp32-typed [N, K] matrix whose bytes are the pre-split fp16 pairs of TtGemmArgs.presplit (see presplit_f32).  The subclass
+    is the marker ops.gemm looks for; row slices / row permutations / contiguous() keep it (and stay valid: the pairing is per row,
+    in aligned groups of 4 columns).  Arithmetic on it is meaningless -- pre-split LAST, after every fold that reads the values."""
+
+
+def presplit_f32(w: torch.Tensor) -> torch.Tensor:
+    """fp32 [N, K] (K % 4 == 0) -> the same shape and element size holding, per aligned group of 4 consecutive k, the eight fp16 values
+    h0 h1 h2 h3 l0 l1 l2 l3 with h = fp16(x 2^-8) and l = fp16((x - 2^8 h) 2^3): what the split16 GEMM (tt_gemm_set_f32_split) forms
+    from every fp32 operand on the fly, done once for operands that are constants of the request (include/ttvdm.h, TtGemmArgs.presplit).
+    Values beyond 2^24 would overflow h, as in the kernel."""
+    if isinstance(w, PreSplitF32):
+        return w
+    if w.dtype != torch.float32 or w.dim() != 2 or w.shape[1] % 4:
+        raise ValueError(f"presplit_f32: fp32 [N, K] with K % 4 == 0 expected, got {tuple(w.shape)} {w.dtype}")
+    n, k = w.shape
+    xs = w.detach().contiguous() * 2.0 ** -8
+    h = xs.to(torch.float16)
+    l = ((xs - h.float()) * 2048.0).to(torch.float16)             # exact residual in fp32, one rounding (the kernel: one fused v_fma_mix)
+    pairs = torch.stack([h.view(n, k // 4, 4), l.view(n, k // 4, 4)], 2)     # [N, K/4, 2, 4] halves = 16 bytes per group
+    return pairs.reshape(n, 2 * k).contiguous().view(torch.float32).as_subclass(PreSplitF32)

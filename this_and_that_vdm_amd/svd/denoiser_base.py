@@ -28,6 +28,42 @@ def as_nchw_view(tok: torch.Tensor, g: Geom) -> torch.Tensor:
     return tok.view(g.n, g.h, g.w, tok.shape[1]).permute(0, 3, 1, 2)
 
 
+# split16 (TT_F32 with split-fp16 products): every packed GEMM weight is a constant of the request, so it is split into its fp16
+# (h, l) pairs ONCE here instead of in every launch (packing.presplit_f32; the kernel then converts the activation operand only --
+# half of its conversion VALU).  Attribute names per leaf class; views are re-derived from their converted base.
+_PRESPLIT_ATTRS = {
+    "ResnetBlock2D": ("w1", "w2", "ws"), "TemporalResnetBlock": ("w1", "w2"), "Downsample2D": ("w",), "Upsample2D": ("w",),
+    "FeedForward": ("wg", "w2"), "BasicTransformerBlock": ("wqkv", "wo1", "wo2"), "TemporalBasicTransformerBlock": ("wqkv", "wo1", "wo2"),
+    "TransformerSpatioTemporalModel": ("w_in", "w_out"),
+}
+
+
+def presplit_packed_weights(root: nn.Module) -> None:
+    from ..packing import presplit_f32
+    for m in root.modules():
+        d = m.__dict__
+        for name in _PRESPLIT_ATTRS.get(type(m).__name__, ()):
+            t = d.get(name)
+            if torch.is_tensor(t) and t.dtype == torch.float32 and t.dim() == 2:
+                d[name] = presplit_f32(t)
+        if type(m).__name__ == "BasicTransformerBlock" and "wqk" in d:       # views of wqkv: Q | K rows, V rows
+            c2 = d["wqk"].shape[0]
+            d["wqk"], d["wv"] = d["wqkv"][:c2], d["wqkv"][c2:]
+        q2 = d.get("q2")
+        if q2 is not None and not q2.is_fused and q2.w.dtype == torch.float32:
+            q2.w, q2._other = presplit_f32(q2.w), None
+    for name in ("_w_in", "_w_out", "_k_w", "_v_w"):
+        t = root.__dict__.get(name)
+        if torch.is_tensor(t) and t.dtype == torch.float32 and t.dim() == 2:
+            root.__dict__[name] = presplit_f32(t)
+    for name in ("_zero", "_zero_mid"):                                     # ControlNet zero-convs: (weight, bias) pairs
+        z = root.__dict__.get(name)
+        if isinstance(z, list):
+            root.__dict__[name] = [(presplit_f32(w), b) if torch.is_tensor(w) and w.dtype == torch.float32 and w.dim() == 2 else (w, b) for w, b in z]
+        elif isinstance(z, tuple) and torch.is_tensor(z[0]) and z[0].dtype == torch.float32 and z[0].dim() == 2:
+            root.__dict__[name] = (presplit_f32(z[0]),) + tuple(z[1:])
+
+
 class DenoiserBase(ModelMixin):
     # None: the parameter dtype if it is 16-bit, else bf16.  torch.float32 selects the reference-precision mode (TT_F32:
     # the same launch sequence on fp32 storage with the exact-fp32 MFMA, ~1/16 of the bf16 rate) used by the parity tests.
@@ -54,7 +90,8 @@ class DenoiserBase(ModelMixin):
         if pl is None:
             pl = self.__dict__["_plist"] = list(self.parameters())
         p0 = pl[0]
-        return (p0.device, self._run_dtype(), sum(p._version for p in pl), p0.data_ptr())
+        # (the TT_F32 product mode decides whether the packed weights are pre-split: toggling it repacks)
+        return (p0.device, self._run_dtype(), sum(p._version for p in pl), p0.data_ptr(), ops.f32_split())
 
     def invalidate_packs(self):
         """Force the next prepare() to repack (call after writing parameters through ``.data`` or an aliasing buffer)."""
@@ -83,6 +120,8 @@ class DenoiserBase(ModelMixin):
         self._film_b = torch.cat(reg.film_b, 0).float().contiguous()
         self._k_w = torch.cat(reg.k_w, 0).to(dtype).contiguous()
         self._v_w = torch.cat(reg.v_w, 0).to(dtype).contiguous()
+        if dtype == torch.float32 and ops.f32_split():
+            presplit_packed_weights(self)
         self._packed_key = self._pack_key()
         self._pack_gen = self._pack_gen + 1
         return self
