@@ -276,8 +276,6 @@ size_t tt_groupnorm_ws_bytes(int32_t nimg, int32_t hw, int32_t c);
 int tt_groupnorm_stats(const void* x0, int32_t c0, const void* x1, int32_t c1, int32_t nimg, int32_t hw,
                        int32_t frames_per_group, const float* gamma, const float* beta, float eps,
                        float* scale, float* shift, void* ws, size_t ws_bytes, int32_t dtype, tt_stream_t stream);
-/* y[n,p,0:c0+c1] = act(x*scale+shift), act = SiLU if silu else identity; y has row stride ldy (>= c0+c1,
- * extra columns untouched). */
 /* GroupNorm(32) (+SiLU) of x [nseg * seg_rows, c] from the tile sums its producer left (TtGemmArgs.stats_out, stat_rows = the
  * tt_gemm_stats_rows of that launch): ONE pass over x, one launch, for per-image statistics (seg_rows = h*w) and for the cross-frame
  * statistics of TemporalResnetBlock (seg_rows = frames*h*w) alike.  seg_rows must be a multiple of stat_rows (a segment is a whole
@@ -287,6 +285,8 @@ int tt_groupnorm_tiles_supported(int32_t seg_rows, int32_t c, int32_t stat_rows,
 int tt_groupnorm_tiles(const void* x, int32_t c, const float* stats, int32_t stat_rows, int32_t nseg, int32_t seg_rows,
                        const float* gamma, const float* beta, float eps, int32_t silu, void* y, int64_t ldy, int32_t dtype,
                        tt_stream_t stream);
+/* y[n,p,0:c0+c1] = act(x*scale+shift), act = SiLU if silu else identity; y has row stride ldy (>= c0+c1,
+ * extra columns untouched). */
 int tt_groupnorm_apply(const void* x0, int32_t c0, const void* x1, int32_t c1, int32_t nimg, int32_t hw,
                        const float* scale, const float* shift, int32_t silu, void* y, int64_t ldy,
                        int32_t dtype, tt_stream_t stream);
@@ -310,12 +310,6 @@ int tt_layernorm(const void* x, int64_t ldx, int32_t rows, int32_t c, const floa
                  float eps, const float* rowvec, int32_t rows_per_vec, int32_t nvec, void* xsum_out,
                  void* y, int64_t ldy, int32_t dtype, tt_stream_t stream);
 
-/* ------------------------------------------------------------------------------------------------
- * small dense layers on <=32 rows, fp32 activations (time / add / FiLM / frame-position MLPs:
- * unet...:416-432, ResnetBlock2D.time_emb_proj, transformer_temporal.py:338):
- *   y[r][n] = act_out( sum_k act_in(x[r][k]) * W[n][k] + bias[n] ),  act: 0 none, 1 SiLU.
- * W is `dtype`, x/y/bias fp32.  accumulate != 0 adds into y.
- * ---------------------------------------------------------------------------------------------- */
 /* Weight packing on the device (packing.zero_sum_round; the LayerNorm-folded projections of Basic / TemporalBasicTransformerBlock reached
  * from transformer_temporal.py:342-365): rounds the rows of w (fp32 [n, k], each summing to ~0) to the 16-bit `dtype` such that every ROUNDED
  * row sums to exactly zero -- binade by binade from `hi` down to max(lo, hi - 48) (the largest / smallest binade exponent of the rounded
@@ -323,6 +317,13 @@ int tt_layernorm(const void* x, int64_t ldx, int32_t rows, int32_t c, const floa
  * bit-identical to the host implementation.  k <= 16384. */
 int tt_zero_sum_round(const float* w, int64_t ldw, int32_t n, int32_t k, int32_t hi, int32_t lo, void* out, int64_t ldo,
                       int32_t dtype, tt_stream_t stream);
+/* ------------------------------------------------------------------------------------------------
+ * small dense layers on <=32 rows, fp32 activations (time / add / FiLM / frame-position MLPs:
+ * unet...:416-432, ResnetBlock2D.time_emb_proj, transformer_temporal.py:338):
+ *   y[r][n] = act_out( sum_k act_in(x[r][k]) * W[n][k] + bias[n] ),  act: 0 none, 1 SiLU.
+ * W is `dtype`, x/y/bias fp32.  accumulate != 0 adds into y.  k % 8 == 0 and k <= 8192 (the activated rows of x are staged
+ * in LDS four at a time: 4 x k fp32; TT_EUNSUPPORTED beyond -- the path's widest MLP input is 1280).
+ * ---------------------------------------------------------------------------------------------- */
 int tt_small_linear(const float* x, int64_t ldx, int32_t rows, int32_t k, const void* w, int64_t ldw, int32_t n,
                     const float* bias, int32_t act_in, int32_t act_out, int32_t accumulate, float* y, int64_t ldy,
                     int32_t dtype, tt_stream_t stream);

@@ -1095,7 +1095,7 @@ def test_gemm_output_statistics_and_groupnorm_from_tiles(ops, dtype, case):
     assert torch.equal(out, plain), "the statistics epilogue must not change the output"
     st = getattr(out, "_tt_stats", None)
     assert st is not None, f"{case}: route without statistics epilogue"
-    sbuf, r = st
+    sbuf, r = st[:2]
     if case == "w320h_conv_64":
         assert r == 64
     elif case.startswith("w320h"):
@@ -1131,3 +1131,15 @@ def test_gemm_output_statistics_and_groupnorm_from_tiles(ops, dtype, case):
     # an in-place overwrite drops the stale sums
     ops.gemm(a, w, out=out, **kw)
     assert not hasattr(out, "_tt_stats")
+    # ... and so does a write through ANY view of the buffer by another ops.* launch (the write ledger in ops.py): the sums stay attached to
+    # the base tensor object, but groupnorm() must not use them -- the statistics pass runs on the values that are there now
+    fresh = ops.gemm(a, w, stats=seg, **kw)
+    assert hasattr(fresh, "_tt_stats")
+    ops.add_scaled(fresh, fresh, 1.0, out=fresh.view(rows, n))          # x <- x + x, written through a VIEW object of the same storage
+    assert hasattr(fresh, "_tt_stats"), "the view write cannot see the base object's attribute"
+    fpg0 = 1 if hw % r == 0 else frames
+    if (fpg0 * hw) % r == 0:
+        y_now = ops.groupnorm(fresh, None, nimg, hw, fpg0, gamma, beta, 1e-5, True)
+        xf = fresh.float()
+        ref_now = F.silu(F.group_norm(xf.view(nimg // fpg0, fpg0 * hw, n).permute(0, 2, 1), 32, gamma, beta, 1e-5)).permute(0, 2, 1).reshape(rows, n)
+        close(y_now, ref_now.cpu(), dtype, scale=2.0)

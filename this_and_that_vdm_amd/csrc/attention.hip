@@ -1067,7 +1067,7 @@ void launch_tattn(const void* qkv, long ldqkv, void* out, long ldo, int batch, i
   if constexpr (D == 64 && Elem<Tag>::ES == 2 && LPU == 16) {
     static int mfma = -1;                                    // TT_TATTN_MFMA=0: the per-lane kernel (A/B)
     if (mfma < 0) { const char* e = getenv("TT_TATTN_MFMA"); mfma = e ? atoi(e) : 1; }
-    if (mfma) {
+    if (mfma && frames <= 16) {                              // (one 16 x 16 MFMA tile of keys x queries per unit: the kernel's own precondition)
       long blocks = (units + 3) / 4;
       if (blocks > 256 * 8) blocks = 256 * 8;                // 8 blocks of 4 waves per CU, grid-stride over the units
       hipLaunchKernelGGL((tattn_mfma_kernel<Tag>), dim3((unsigned)blocks), dim3(256), 0, st, (const char*)qkv, ldqkv, (char*)out, ldo, batch, frames, hw,
@@ -1105,6 +1105,10 @@ extern "C" int tt_attention(const TtAttnArgs* a, tt_stream_t stream) {
   const int eso = a->dtype == TT_F32 ? 4 : 2;
   if ((a->q && ((a->ldq * es) & 15)) || ((a->ldk * es) & 15) || ((a->ldvt * es) & 15) || ((a->ldo * eso) & 15) || (!a->v_rows && ((a->v_seq_stride * es) & 15)))
     TT_FAIL(TT_EINVAL, "tt_attention: strides must keep 16-byte chunks aligned");
+  // base pointers too: K / V tiles go to LDS by 16-byte DMA, the v_rows route and the outputs use 16-byte vector accesses (a column
+  // slice of a fused Q | K | V buffer offset by a non-multiple of 8 elements would otherwise be read misaligned instead of refused)
+  if ((((size_t)a->q | (size_t)a->k | (size_t)a->vt | (size_t)a->out) & 15))
+    TT_FAIL(TT_EINVAL, "tt_attention: q, k, vt and out must start on 16-byte boundaries");
   AttnP p;
   p.q = (const char*)a->q; p.ldq = a->ldq; p.k = (const char*)a->k; p.ldk = a->ldk;
   p.vt = (const char*)a->vt; p.ldvt = a->ldvt; p.out = (char*)a->out; p.ldo = a->ldo;
@@ -1154,6 +1158,7 @@ extern "C" int tt_temporal_attention(const void* qkv, int64_t ldqkv, void* out, 
   if (frames <= 0 || frames > 32) TT_FAIL(TT_EUNSUPPORTED, "tt_temporal_attention: frames %d (1..32)", frames);
   if (dtype != TT_BF16 && dtype != TT_F16 && dtype != TT_F32) TT_FAIL(TT_EINVAL, "tt_temporal_attention: bad dtype");
   if (((ldqkv * (dtype == TT_F32 ? 4 : 2)) & 15) || ((ldo * (dtype == TT_F32 ? 4 : 2)) & 15)) TT_FAIL(TT_EINVAL, "tt_temporal_attention: strides");
+  if ((((size_t)qkv | (size_t)out) & 15)) TT_FAIL(TT_EINVAL, "tt_temporal_attention: qkv and out must start on 16-byte boundaries");
   hipStream_t st = (hipStream_t)stream;
 #define TT_TA(TAG, D, L) launch_tattn<TAG, D, L>(qkv, ldqkv, out, ldo, batch, frames, hw, heads, st)
   if (dtype == TT_BF16) {

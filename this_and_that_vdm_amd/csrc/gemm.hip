@@ -86,6 +86,7 @@ int forced_split() {
 //   * few tiles but a long K (convs at the two coarsest levels): 128x128 tiles with the K loop split over S
 //     workgroups, fp32 slabs reduced in fixed order by a second kernel.
 struct Plan { int cfg, splitk; };
+
 // `wide_ok`: the 256x128 tile pays for tall-and-wide problems (GEGLU projections, fused QKV) unless the epilogue reads
 // per-row tensors (residual / blend / row vector): its 128-VGPR budget has no room to preload them, so they would be read
 // between the stores (measured: 16 us epilogue instead of 3)
@@ -125,6 +126,10 @@ Plan make_plan(int m, int n, long ktot, bool allow_split, bool wide_ok = true, b
     static int small64 = -1;
     if (small64 < 0) { const char* e = getenv("TT_GEMM_SMALL64"); small64 = e ? atoi(e) : 2; }
     if (small64 && (small64 != 2 || (m <= 64 && n >= 4096)) && mode0 && ktot <= 2048 && (long)ceil_div(m, 64) * ceil_div(n, 64) <= 512) { pl.cfg = 2; return pl; }   // (2: only the <= 64-row tails)
+    // (Round 6, tools/coarse_conv_probe.py / profiles/r6_coarse_conv_probe.txt: on cold weights in isolation the 70-tile convs of the coarsest
+    // level are 18-20 % faster as two resident double-buffered 8-wave workgroups per CU with six K slices -- cfg 11: 53.6 -> 43.9 us,
+    // 92.7 -> 74.2 us, reduction pass included -- and the step does not move: 28.97 / 29.06 vs 29.05 / 29.00 ms, one call, interleaved.
+    // Not routed: once more, an isolated sweep does not predict the step.)
     pl.cfg = (deep == 2 && k128) ? 20 : 16;
     long s = allow_split ? 256 / b128 : 1;
     if (s > kt / 8) s = kt / 8;

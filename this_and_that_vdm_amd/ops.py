@@ -34,6 +34,33 @@ def _prof_end(start, name, flops, shape=None):
         PROFILE.append((name, flops, start, e, shape))
 
 
+# ---- producer -> GroupNorm hand-off (gemm(..., stats=) / gemm(..., gn=) -> groupnorm()).  The producer's per-tile column sums (or the
+# tensor its reduction pass already normalised) travel with the OUTPUT TENSOR OBJECT as `_tt_stats` / `_tt_gn`, because producer and
+# consumer sit in different modules (a ResBlock's conv feeds the next block's norm).  What makes that safe is the write ledger below:
+# every ops.* function that writes a tensor through a raw pointer records a serial number for the tensor's STORAGE, the hand-off stores
+# the serial of the launch that produced the sums, and groupnorm() uses them only if no ops.* launch has written that storage since
+# (a write through ANY view of the buffer -- gemm(out=view), attention(out=), add_rowvec(out=), add_scaled(out=), nchw_to_tokens(out=) --
+# bumps the serial) and the tensor still has the pointer and shape it had then.  Stale sums are ignored (statistics pass), never used.
+import itertools
+
+_SERIAL = itertools.count(1)
+_LAST_WRITE = {}
+
+
+def _wrote(t: torch.Tensor) -> int:
+    """record a raw-pointer write to (a view of) t's storage; returns the write's serial number"""
+    n = next(_SERIAL)
+    _LAST_WRITE[t.untyped_storage().data_ptr()] = n
+    for name in ("_tt_stats", "_tt_gn"):
+        if hasattr(t, name):
+            delattr(t, name)
+    return n
+
+
+def _handoff_valid(t: torch.Tensor, serial: int, ptr: int, shape) -> bool:
+    return _LAST_WRITE.get(t.untyped_storage().data_ptr()) == serial and t.data_ptr() == ptr and tuple(t.shape) == shape
+
+
 _WS = {}
 _WS_RETIRED = []          # outgrown buffers stay allocated: a captured hipGraph may still hold their address
 WS_FLOOR_BYTES = 64 << 20
@@ -167,10 +194,6 @@ def gemm(a0: torch.Tensor, w: torch.Tensor, *, a1: Optional[torch.Tensor] = None
     if need:
         ws = _workspace(need, a0.device)
         g.ws, g.ws_bytes = ws.data_ptr(), ws.numel()
-    if hasattr(out, "_tt_stats"):
-        del out._tt_stats                                   # `out` is being overwritten: sums attached by an earlier launch are stale
-    if hasattr(out, "_tt_gn"):
-        del out._tt_gn
     sbuf = gnbuf = None
     if stats and gn is not None and GN_FUSED:
         g.stats_seg = int(stats)
@@ -187,10 +210,11 @@ def gemm(a0: torch.Tensor, w: torch.Tensor, *, a1: Optional[torch.Tensor] = None
             g.stats_out = sbuf.data_ptr()
     ev = _prof_begin()
     check(lib.tt_gemm(C.byref(g), _stream()), "tt_gemm")
+    serial = _wrote(out)                                    # `out` was overwritten: sums attached by an earlier launch are dropped
     if sbuf is not None:
-        out._tt_stats = (sbuf, srows)
+        out._tt_stats = (sbuf, srows, serial, out.data_ptr(), tuple(out.shape))
     if gnbuf is not None:
-        out._tt_gn = (gnbuf, gn[0].data_ptr(), gn[1].data_ptr(), float(gn[2]), bool(gn[3]), int(stats))
+        out._tt_gn = (gnbuf, gn[0].data_ptr(), gn[1].data_ptr(), float(gn[2]), bool(gn[3]), int(stats), serial, out.data_ptr(), tuple(out.shape))
     if ev is not None:
         cfg = (C.c_int32 * 7)()
         lib.tt_gemm_plan(C.byref(g), cfg)
@@ -245,6 +269,7 @@ def conv3x3(x0, x1, w, nimg: int, h: int, wd: int, *, gn=None, silu: bool = True
     a.out, a.ldo, a.dtype = _p(out), out.stride(0), _code(x0.dtype)
     ev = _prof_begin()
     check(lib.tt_conv3x3(C.byref(a), _stream()), "tt_conv3x3")
+    _wrote(out)
     if ev is not None:
         k = 9 * (a.c0 + a.c1)
         _prof_end(ev, f"conv_patch_kernel<{_TAG[a.dtype]}>", 2.0 * nimg * h * wd * n * k, shape=(1, nimg * h * wd, n, k, 0, int(residual is not None)))
@@ -290,6 +315,7 @@ def attention(q, k, vt, out, *, nseq, lq, heads, head_dim, mask, lk, k_seq_strid
     a.v_rows = int(bool(v_rows))
     ev = _prof_begin()
     check(lib.tt_attention(C.byref(a), _stream()), "tt_attention")
+    _wrote(out)
     if ev is not None:
         tag = _TAG[a.dtype]
         kname = f"attn8_kernel<{tag}, {head_dim}>" if fp8 else f"attn_kernel<{tag}, {head_dim}, {mask}{', true' if qx is not None else ''}{', false, true' if v_rows else ''}>"
@@ -302,6 +328,7 @@ def temporal_attention(qkv, out, *, batch, frames, hw, heads, head_dim):
     lib = _lib.load()
     check(lib.tt_temporal_attention(_p(qkv), qkv.stride(0), _p(out), out.stride(0), batch, frames, hw, heads, head_dim,
                                     _code(qkv.dtype), _stream()), "tt_temporal_attention")
+    _wrote(out)
     return out
 
 
@@ -328,6 +355,7 @@ def groupnorm_apply(x0, x1, nimg, hw, scale, shift, silu: bool, out=None):
         out = torch.empty((nimg * hw, c0 + c1), dtype=x0.dtype, device=x0.device)
     check(lib.tt_groupnorm_apply(_p(x0), c0, _p(x1), c1, nimg, hw, _p(scale), _p(shift), int(silu), _p(out), out.stride(0),
                                  _code(x0.dtype), _stream()), "tt_groupnorm_apply")
+    _wrote(out)
     return out
 
 
@@ -346,8 +374,10 @@ GN_TILES = os.environ.get("TT_GN_TILES", "1") != "0"
 GN_TILES_SEG = os.environ.get("TT_GN_TILES_SEG", "1") != "0"       # ... also on the split-K routes (coarse levels) and with per-wave-row sums of the tiled template (A/B)
 GN_FUSED = os.environ.get("TT_GN_FUSED", "1") != "0"        # GroupNorm inside the split-K reduction pass (TtGemmArgs.gn_out), A/B
 GN_TILES_MAX_ELEMS = int(os.environ.get("TT_GN_TILES_MAX_ELEMS", str(17 << 20)))
-_GN_EMULATE = os.environ.get("TT_GN_EMULATE", "0") == "1"
-_GN_EMU_CACHE = {}
+# (the "apply-only consumer" timing experiment of round 5 -- groupnorm() with scale 1 / shift 0, wrong numbers -- lives in
+# tools/gn_emulate.py as a monkeypatch now: a leaked TT_GN_EMULATE=1 can no longer corrupt every GroupNorm silently)
+if os.environ.get("TT_GN_EMULATE", "0") == "1":
+    raise RuntimeError("TT_GN_EMULATE is no longer read by the library (it produced wrong numbers by design): use tools/gn_emulate.py")
 
 
 def groupnorm(x0, x1, nimg, hw, frames_per_group, gamma, beta, eps, silu: bool):
@@ -356,16 +386,13 @@ def groupnorm(x0, x1, nimg, hw, frames_per_group, gamma, beta, eps, silu: bool):
     lib = _lib.load()
     c0 = x0.shape[-1]
     c1 = 0 if x1 is None else x1.shape[-1]
-    if _GN_EMULATE:          # timing experiment only (wrong numbers): what a statistics-free consumer would cost -- one apply launch
-        key = (nimg, c0 + c1, x0.device)
-        ss = _GN_EMU_CACHE.get(key)
-        if ss is None:
-            ss = _GN_EMU_CACHE[key] = (torch.ones((nimg, c0 + c1), dtype=torch.float32, device=x0.device), torch.zeros((nimg, c0 + c1), dtype=torch.float32, device=x0.device))
-        return groupnorm_apply(x0, x1, nimg, hw, ss[0], ss[1], silu)
     fz = getattr(x0, "_tt_gn", None) if x1 is None else None
-    if fz is not None and fz[1:] == (gamma.data_ptr(), beta.data_ptr(), float(eps), bool(silu), frames_per_group * hw):
+    if fz is not None and fz[1:6] == (gamma.data_ptr(), beta.data_ptr(), float(eps), bool(silu), frames_per_group * hw) and \
+            _handoff_valid(x0, *fz[6:]):
         return fz[0]                                         # the producer's reduction pass already normalised (gemm(..., gn=))
     st = getattr(x0, "_tt_stats", None) if (GN_TILES and x1 is None) else None
+    if st is not None and not _handoff_valid(x0, *st[2:]):
+        st = None                                            # something wrote the buffer after the producer: statistics pass instead
     if st is not None and nimg % frames_per_group == 0 and x0.is_contiguous() and st[0].shape[2] == c0 and \
             lib.tt_groupnorm_tiles_supported(frames_per_group * hw, c0, st[1], _code(x0.dtype)):
         # the producer of x0 left per-tile column sums: one pass over x0, one launch, per-image and cross-frame statistics alike
@@ -405,13 +432,10 @@ def add_rowvec(x, rowvec, rows_per_vec: int, nvec: int, out=None):
     rows, c = x.shape
     assert x.stride(1) == 1 and rowvec.dtype == torch.float32 and rowvec.stride(1) == 1
     y = torch.empty((rows, c), dtype=x.dtype, device=x.device) if out is None else out
-    if hasattr(y, "_tt_stats"):
-        del y._tt_stats
-    if hasattr(y, "_tt_gn"):
-        del y._tt_gn
     assert y.shape == x.shape and y.stride(1) == 1 and y.dtype == x.dtype
     check(lib.tt_add_rowvec(_p(x), x.stride(0), rows, c, _p(rowvec), rowvec.stride(0), rows_per_vec, nvec, _p(y), y.stride(0),
                             _code(x.dtype), _stream()), "tt_add_rowvec")
+    _wrote(y)
     return y
 
 
@@ -434,6 +458,7 @@ def softmax_rows(x, dtype, cols: Optional[int] = None, out=None):
         raise ValueError(f"softmax_rows: output needs >= {cols_pad} columns, got {out.shape[1]}")
     check(lib.tt_softmax_rows(_p(x), x.stride(0), rows, cols, _p(out), out.stride(0), out.shape[1], _code(dtype), _stream()),
           "tt_softmax_rows")
+    _wrote(out)
     return out
 
 
@@ -446,6 +471,7 @@ def small_linear(x, w, bias=None, act_in=False, act_out=False, out=None, accumul
     assert x.dtype == torch.float32 and out.dtype == torch.float32
     check(lib.tt_small_linear(_p(x), x.stride(0), rows, k, _p(w), w.stride(0), n, _p(bias), int(act_in), int(act_out),
                               int(accumulate), _p(out), out.stride(0), _code(w.dtype), _stream()), "tt_small_linear")
+    _wrote(out)
     return out
 
 
@@ -493,6 +519,7 @@ def nchw_to_tokens(src, dtype, ld=None, out=None):
     assert out.dtype == dtype and out.stride(1) == 1
     check(lib.tt_nchw_to_tokens(_p(src), int(src.dtype == torch.float32), n, c, h * w, _p(out), out.stride(0), _code(dtype),
                                 _stream()), "tt_nchw_to_tokens")
+    _wrote(out)
     return out
 
 
@@ -516,4 +543,5 @@ def add_scaled(a, b, scale=1.0, out=None):
     if out is None:
         out = torch.empty_like(a)
     check(lib.tt_add_scaled(_p(a), _p(b), scale, _p(out), a.numel(), _code(a.dtype), _stream()), "tt_add_scaled")
+    _wrote(out)
     return out

@@ -84,8 +84,10 @@ class DenoiserBase(ModelMixin):
         # _version catches in-place updates and load_state_dict; data_ptr catches `.data` re-homing (dist.flat_param_buffer),
         # whose later writes through the flat buffer do NOT bump _version -- dist.broadcast_model_ also invalidates explicitly
         # (the parameter LIST is cached: walking the module tree of a 1.5 B-parameter UNet costs ~0.9 ms per call and begin() / step()
-        # ask several times per request -- 8 ms of host time per begin() before round 5; _apply / load_state_dict / invalidate_packs
-        # drop the list, and its length is compared against the module's parameter count on every repack)
+        # ask several times per request -- 8 ms of host time per begin() before round 5.  _apply / load_state_dict / invalidate_packs and
+        # every repack drop the list.  What the key does NOT see: a parameter REPLACED by assignment (`mod.weight = nn.Parameter(..)`,
+        # an adapter merge that swaps tensors) -- the cached list still holds the old object.  Call invalidate_packs() after replacing
+        # parameter objects; in-place updates (`.copy_`, optimizer steps, load_state_dict) need nothing.)
         pl = self.__dict__.get("_plist")
         if pl is None:
             pl = self.__dict__["_plist"] = list(self.parameters())
@@ -94,7 +96,8 @@ class DenoiserBase(ModelMixin):
         return (p0.device, self._run_dtype(), sum(p._version for p in pl), p0.data_ptr(), ops.f32_split())
 
     def invalidate_packs(self):
-        """Force the next prepare() to repack (call after writing parameters through ``.data`` or an aliasing buffer)."""
+        """Force the next prepare() to repack.  REQUIRED after replacing parameter objects by assignment (`mod.weight = nn.Parameter(..)`)
+        and after writing parameters through ``.data`` or an aliasing buffer: neither bumps a `_version` the pack key can see."""
         self._packed_key = None
         self.__dict__.pop("_plist", None)
 

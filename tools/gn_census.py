@@ -23,7 +23,7 @@ def main():
     def spy(x0, x1, nimg, hw, fpg, *a, **k):
         st = getattr(x0, "_tt_stats", None)
         fz = getattr(x0, "_tt_gn", None) if x1 is None else None
-        how = "by the producer's split-K reduction pass" if fz is not None and fz[5] == fpg * hw else "two sources" if x1 is not None else (f"tiles of {st[1]} rows" if st is not None and (fpg * hw) % st[1] == 0 else "no sums attached")
+        how = "by the producer's split-K reduction pass" if fz is not None and fz[5] == fpg * hw else "two sources" if x1 is not None else (f"tiles of {st[1]} rows" if st is not None and (fpg * hw) % st[1] == 0 and ops._handoff_valid(x0, *st[2:]) else "no sums attached")
         seen[(hw, x0.shape[-1] + (0 if x1 is None else x1.shape[-1]), "cross-frame" if fpg > 1 else "per image", how)] += 1
         return real(x0, x1, nimg, hw, fpg, *a, **k)
     ops.groupnorm = spy
