@@ -41,7 +41,7 @@ PEAK_TFLOPS_SPLIT16 = PEAK_TFLOPS / 3    # split16: every product block is three
 TOLERANCE_MODE_FILE = "r6_bench_lo_split16.json"   # the bench line of the mode that meets rtol 1e-3 / atol 1e-4 (python bench.py --dtype split16)
 WINDOWS = 3                   # timed windows of --steps steps each; ms_per_step is their median
 FRAMES, CTX_TOKENS, CTX_DIM, STEPS_PER_REQUEST = 14, 78, 1024, 25
-TRAFFIC_FILE = "r5_hbm_traffic.json"     # written by tools/profile_round.sh (rocprofv3 --pmc passes), stamped with the kernel-source hash
+TRAFFIC_FILE = "r6_hbm_traffic.json"     # written by tools/profile_round.sh (rocprofv3 --pmc passes), stamped with the kernel-source hash
 
 
 def csrc_hash() -> str:
@@ -268,7 +268,11 @@ def block_main(a, dtype, device, peak) -> int:
                                    "78 context tokens (uncond context all zero), hipGraph replay", "spatial_self_attention": a.attn,
                        "finite_output": bool(torch.isfinite(out.float()).all().item()), "block_tflop_algorithmic": flops / 1e12,
                        "mfma_kernels": {k: {"launches": v[0], "tflop": v[1] / 1e12, "ms": v[2] * 1e3, "tflops": v[1] / v[2] / 1e12}
-                                        for k, v in sorted(agg.items(), key=lambda kv: -kv[1][2])}},
+                                        for k, v in sorted(agg.items(), key=lambda kv: -kv[1][2])},
+                       # every GEMM / attention launch of one forward in launch order (eager, event-timed one by one): the input of
+                       # DESIGN.md 6.C (ceiling analysis); shape = (mode, M, N, K, geglu, residual) or ("attn", batch x heads, Lq, Lk, mask, 0)
+                       "launch_list": [{"kernel": name, "shape": list(shape) if shape else None, "gflop": fl / 1e9, "us": e0.elapsed_time(e1) * 1e3}
+                                       for name, fl, e0, e1, shape in rec]},
             "roofline": {"bound": "mfma", "kernel": "whole block (all launches of one forward)", "achieved": flops / (ms * 1e-3) / 1e12,
                          "peak": peak, "unit": "TFLOP/s", "frac": flops / (ms * 1e-3) / 1e12 / peak, "traffic": None},
             "cpu_baseline": None}

@@ -322,6 +322,11 @@ static Plan plan_for(const TtGemmArgs* a) {
     // Other shapes of the big tile, each one gpurun call against 106-108 ms / step for this one: 128 x 128 x 16 with a 4-deep / 3-deep ring
     // (three / two tiles in flight instead of one) 112.7 / 112.0; x 32 with a 3-deep ring (96 KiB: one workgroup per CU) 135.5; 8 waves
     // as 4 x 2 / 2 x 4 (wave tiles 32 x 64 / 64 x 32 at a 128-register budget) 123.4 / 234.2; 128 x 64 x 32, 3-deep 127.7.
+    // (4 waves as 4 x 1 -- every A fragment converted by one wave instead of two -- 105.1 -> 104.0 ms, within the noise; as 1 x 4 149.6.)
+    // Where the time goes (ablation builds `make variant DEFS=-DTT_SPLIT_ABL=1|2|3`, wrong numbers, one call): 105.4 ms as built; without
+    // any conversion 74.8; with one MFMA per product block instead of three 75.1; with neither 65.9 -- conversions and the two extra MFMAs
+    // cost ~9 ms each on their own and ~40 ms together: inside one wave they run back to back (the fragment consumers are pinned by
+    // sched_barrier: the raw-read hazard of gemm_kernel.h), so the matrix pipe idles while a wave converts.
     return Plan{plan_f32(a->m, a->n, f32_split() ? split_min : 256), 1};
   }
   const int taps = a->mode == 1 ? 9 : (a->mode == 2 ? 3 : 1);

@@ -556,7 +556,11 @@ void gemm_kernel(const GemmP p) {
     asm("v_fma_mixhi_f16 %0, %1, %2, %3 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "+v"(l23) : "v"(h.y), "v"(kM2048), "v"(e23.y));
     l = make_uint2(l01, l23);
   };
+#if defined(TT_SPLIT_ABL) && (TT_SPLIT_ABL & 1)      // ablation build (timing only, wrong numbers): no conversions at all
+  const bool pre_a = true, pre_b = true;
+#else
   const bool pre_a = SPLIT && (p.presplit & 1), pre_b = SPLIT && (p.presplit & 2);      // launch-uniform
+#endif
   auto mma = [&](const raw_u32x4_t (&af)[FM], const raw_u32x4_t (&bf)[FN], int phase) {
     if constexpr (LN == 1) {
 #pragma unroll
@@ -593,9 +597,13 @@ void gemm_kernel(const GemmP p) {
         for (int i = 0; i < FM; ++i)
 #pragma unroll
           for (int j = 0; j < FN; ++j) {
+#if !defined(TT_SPLIT_ABL) || !(TT_SPLIT_ABL & 2)      // ablation bit 1: one MFMA per product block instead of three
             accx[i][j] = Cvt<f16_tag>::mfma32(bl[j], ah[i], accx[i][j]);
+#endif
             acc[i][j] = Cvt<f16_tag>::mfma32(bh[j], ah[i], acc[i][j]);
+#if !defined(TT_SPLIT_ABL) || !(TT_SPLIT_ABL & 2)
             accx[i][j] = Cvt<f16_tag>::mfma32(bh[j], al[i], accx[i][j]);
+#endif
           }
       }
       __builtin_amdgcn_sched_barrier(0);     // the conversions read raw-asm fragment registers: same pinning as the statistics below
