@@ -593,18 +593,24 @@ void gemm_kernel(const GemmP p) {
           split4(bf[j], pre_b, h, l);
           bh[j] = make_uint4(sp_bh[j].x, sp_bh[j].y, h.x, h.y); bl[j] = make_uint4(sp_bl[j].x, sp_bl[j].y, l.x, l.y);
         }
+        // three sweeps over the blocks, so that the two MFMAs into one cross-term accumulator sit FM x FN x 2 instructions apart
+        // (back to back they wait for each other's result)
+#if !defined(TT_SPLIT_ABL) || !(TT_SPLIT_ABL & 2)      // ablation bit 1: one MFMA per product block instead of three
 #pragma unroll
         for (int i = 0; i < FM; ++i)
 #pragma unroll
-          for (int j = 0; j < FN; ++j) {
-#if !defined(TT_SPLIT_ABL) || !(TT_SPLIT_ABL & 2)      // ablation bit 1: one MFMA per product block instead of three
-            accx[i][j] = Cvt<f16_tag>::mfma32(bl[j], ah[i], accx[i][j]);
+          for (int j = 0; j < FN; ++j) accx[i][j] = Cvt<f16_tag>::mfma32(bl[j], ah[i], accx[i][j]);
 #endif
-            acc[i][j] = Cvt<f16_tag>::mfma32(bh[j], ah[i], acc[i][j]);
+#pragma unroll
+        for (int i = 0; i < FM; ++i)
+#pragma unroll
+          for (int j = 0; j < FN; ++j) acc[i][j] = Cvt<f16_tag>::mfma32(bh[j], ah[i], acc[i][j]);
 #if !defined(TT_SPLIT_ABL) || !(TT_SPLIT_ABL & 2)
-            accx[i][j] = Cvt<f16_tag>::mfma32(bh[j], al[i], accx[i][j]);
+#pragma unroll
+        for (int i = 0; i < FM; ++i)
+#pragma unroll
+          for (int j = 0; j < FN; ++j) accx[i][j] = Cvt<f16_tag>::mfma32(bh[j], al[i], accx[i][j]);
 #endif
-          }
       }
       __builtin_amdgcn_sched_barrier(0);     // the conversions read raw-asm fragment registers: same pinning as the statistics below
     } else {
