@@ -842,7 +842,7 @@ def test_gemm_every_tile_configuration(ops, cfg):
 
 @pytest.mark.parametrize("dtype", DTYPES16)
 @pytest.mark.parametrize("m", [4101, 50176, 3 * 8192 - 31])
-@pytest.mark.parametrize("epi", ["plain", "bias_res", "blend"])
+@pytest.mark.parametrize("epi", ["plain", "bias_res", "blend", "rowvec_parity", "rowvec_two_groups", "rowvec_blend"])
 def test_gemm_square_320_streaming_kernel(ops, dtype, m, epi):
     """the W-in-registers persistent kernel that serves the 320 x 320 linears of the finest level (M >= 4096)."""
     import ctypes as C
@@ -868,6 +868,29 @@ def _run_square_320(ops, lib, dtype, m, epi, a, w, bias, res):
     assert lib.tt_gemm_plan(C.byref(g), cfg) == 0 and cfg[0] == 32 and cfg[1] == 320, list(cfg)
     out = torch.full((m + 8, n), 7.0, dtype=dtype, device="cuda")
     ref = a.float() @ w.float().T
+    if epi.startswith("rowvec"):
+        # round 6: a row vector with two distinct rows rides on the residual form -- even / odd rows (the temporal block's output
+        # projection, rowvec_rows = 1, rowvec_mod = 2) or two row groups (the zero-context bias per CFG half; a multiple of 32 rows)
+        rv = rnd(2, n, dtype=torch.float32, seed=4)
+        half = (m // 2 + 31) // 32 * 32
+        if epi == "rowvec_parity":
+            kw, sel = dict(rowvec_rows=1, rowvec_mod=2), (torch.arange(m) & 1)
+        else:
+            kw, sel = dict(rowvec_rows=half), (torch.arange(m) >= half).long()
+        g.rowvec, g.rowvec_rows, g.rowvec_mod, g.residual, g.ld_rowvec, g.ld_res = 16, kw["rowvec_rows"], kw.get("rowvec_mod", 0), 16, n, n
+        assert lib.tt_gemm_plan(C.byref(g), cfg) == 0 and cfg[0] == 32 and cfg[1] == 320, list(cfg)      # still the streaming kernel
+        r = res.cuda()
+        extra = dict(blend=r, alpha=0.3) if epi == "rowvec_blend" else {}
+        ops.gemm(a.cuda(), w.cuda(), bias=bias.cuda(), acc_scale=0.5, rowvec=rv.cuda(), residual=r, out=out[:m], **kw, **extra)
+        ref = (ref + bias) * 0.5 + rv[sel] + res.float()
+        if extra:
+            ref = 0.3 * res.float() + 0.7 * ref
+        close(out[:m], ref, dtype, scale=2.0)
+        assert (out[m:] == 7.0).all()
+        g3 = _lib.TtGemmArgs()                                   # three groups: not this kernel
+        g3.m, g3.n, g3.k0, g3.mode, g3.rowvec, g3.rowvec_rows, g3.residual, g3.ld_rowvec, g3.ld_res = m, n, k, 0, 16, (m // 3 + 31) // 32 * 32, 16, n, n
+        assert lib.tt_gemm_plan(C.byref(g3), cfg) == 0 and cfg[0] != 32
+        return
     if epi == "plain":
         ops.gemm(a.cuda(), w.cuda(), out=out[:m])
     elif epi == "bias_res":

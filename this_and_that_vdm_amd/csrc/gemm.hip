@@ -158,6 +158,15 @@ extern "C" int tt_gemm_set_tile_override(int32_t cfg) {
   return TT_OK;
 }
 
+// a row vector the streaming kernel can carry: at most two distinct rows over the launch (both preloaded), on the residual form
+static bool sq320_rowvec_ok(const TtGemmArgs* a) {
+  if (!a->rowvec) return true;
+  static int rv = -1;
+  if (rv < 0) { const char* e = getenv("TT_SQ320_ROWVEC"); rv = e ? atoi(e) : 1; }
+  if (!rv || !a->residual) return false;
+  if (a->rowvec_mod == 2 && a->rowvec_rows == 1) return true;
+  return a->rowvec_mod == 0 && a->rowvec_rows >= 32 && a->rowvec_rows % 32 == 0 && (long)a->rowvec_rows * 2 >= a->m;
+}
 static int g_sq320 = -1;
 extern "C" int tt_gemm_set_streaming_square(int32_t on) {
   g_sq320 = on == 2 ? 2 : (on ? 1 : 0);          // 2: by size (the default)
@@ -168,9 +177,11 @@ bool sq320_ok(const TtGemmArgs* a) {
   // 0 off, 1 on, 2 (default) by size: at 64x112 latents (200 704 rows: 784 big tiles = 3.06 rounds of 196) the 32-row streaming kernel wins
   // (block l0hi 5.46 -> 5.39 ms, fp8 4.995 -> 4.91; 512x896 step 109.6 -> 109.1 ms), at 32x56 it loses (29.04 -> 29.32 ms): one call each, interleaved
   if (g_sq320 < 0) { const char* e = getenv("TT_GEMM_SQ320"); g_sq320 = e ? atoi(e) : 2; }
-  if (g_sq320 == 2 && a->m < 131072) return false;
+  static int min_rows = -1;
+  if (min_rows < 0) { const char* e = getenv("TT_SQ320_MIN_ROWS"); min_rows = e ? atoi(e) : 131072; }
+  if (g_sq320 == 2 && a->m < min_rows) return false;
   return g_sq320 && a->dtype != TT_F32 && !a->ln_fold && !a->out_fp8 && forced_cfg() < 0 && a->mode == 0 && a->k1 == 0 && a->k0 == SQ_K && a->n == SQ_N && a->m >= 4096 &&
-         !a->geglu && !a->rowvec && !a->out_f32 && !a->out_col_hw &&
+         !a->geglu && sq320_rowvec_ok(a) && !a->out_f32 && !a->out_col_hw &&
          (!a->blend || (a->blend == a->residual && a->ld_blend == a->ld_res));
 }
 // The persistent big-tile kernel (gemm_pp.hip) takes tall-and-wide Linear problems without per-row epilogue operands when every CU

@@ -1073,7 +1073,10 @@ static_assert(SQ_ROWS * SQ_CPR % SQ_NT == 0 && SQ_CPR % 8 == 0, "sq320 staging")
 __device__ __forceinline__ int sq_swz(int row) { return (row >> 1) & 7; }     // 640-byte rows: see tile_swz
 __device__ __forceinline__ int sq_off(int row, int chunk) { return (row * SQ_CPR + (chunk ^ sq_swz(row))) << 4; }
 
-template <typename Tag, bool HAS_RES>
+// HAS_RV (round 6): a row vector with at most TWO distinct rows over the launch -- the even / odd form (rowvec_rows = 1, rowvec_mod = 2: the temporal
+// block's output projection) or two groups of rowvec_rows rows (a multiple of 32: the zero-context bias per CFG half) -- both rows are loaded ONCE
+// before the tile loop (a load inside it would sit in the counted vmcnt stream of the DMA ring) and selected per row by arithmetic.
+template <typename Tag, bool HAS_RES, bool HAS_RV = false>
 __global__ __launch_bounds__(SQ_NT) void sq320_kernel(const GemmP p) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   constexpr int G = HAS_RES ? 2 * SQ_PASSES : SQ_PASSES;       // DMA instructions per thread per ring slot
@@ -1102,6 +1105,13 @@ __global__ __launch_bounds__(SQ_NT) void sq320_kernel(const GemmP p) {
   const int qq = lane & 7, rr_ = lane >> 3;                    // epilogue layout: 8 quads per 32-column row, 8 rows per pass
   const int gn = wid * 32 + qq * 4;
   const float4 b4 = ld128f(make_rsrc(p.bias, p.bias_bytes), gn * 4);
+  float4 rv0 = make_float4(0.f, 0.f, 0.f, 0.f), rv1 = rv0;
+  const bool rv_parity = HAS_RV && p.rowvec_mod == 2;           // row r takes rv[r & 1]; otherwise rv[r >= rowvec_rows]
+  if constexpr (HAS_RV) {
+    const __amdgpu_buffer_rsrc_t r_rv = make_rsrc(p.rowvec, p.rowvec_bytes);
+    rv0 = ld128f(r_rv, gn * 4);
+    rv1 = ld128f(r_rv, (int)((p.ld_rowvec + gn) * 4));           // (one group only: beyond the descriptor -> zeros, never selected)
+  }
   const float alpha = p.blend ? p.alpha : 0.0f, one_m_alpha = 1.0f - alpha;
   const __amdgpu_buffer_rsrc_t r_out = make_rsrc(p.out, p.out_bytes);
 
@@ -1193,9 +1203,15 @@ __global__ __launch_bounds__(SQ_NT) void sq320_kernel(const GemmP p) {
       float v[4], r4[4];
       unpack4<Tag>(make_uint2(rq[pass].x, rq[pass].y), r4);
       const float bb[4] = {b4.x, b4.y, b4.z, b4.w};
-#pragma unroll
-      for (int e = 0; e < 4; ++e) v[e] = alpha * r4[e] + one_m_alpha * ((t4[e] + bb[e]) * p.acc_scale + r4[e]);
       const int gm = m0 + r;
+      float rv[4] = {0.f, 0.f, 0.f, 0.f};
+      if constexpr (HAS_RV) {
+        const bool second = rv_parity ? (gm & 1) != 0 : gm >= p.rowvec_rows;
+        const float4 f = second ? rv1 : rv0;
+        rv[0] = f.x; rv[1] = f.y; rv[2] = f.z; rv[3] = f.w;
+      }
+#pragma unroll
+      for (int e = 0; e < 4; ++e) v[e] = alpha * r4[e] + one_m_alpha * ((t4[e] + bb[e]) * p.acc_scale + rv[e] + r4[e]);
       st64(r_out, gm < p.m ? (int)(((long)gm * p.ldo + gn) * 2) : kInv, pack2<Tag>(v[0], v[1]), pack2<Tag>(v[2], v[3]));
     }
   };
@@ -1461,14 +1477,14 @@ void launch_cfg(GemmP& p, hipStream_t st) {
   }
 }
 
-template <typename Tag, bool HAS_RES>
+template <typename Tag, bool HAS_RES, bool HAS_RV = false>
 void launch_sq320(const GemmP& p, hipStream_t st) {
   constexpr size_t lds = (size_t)(HAS_RES ? 3 * 2 * SQ_TILE_BYTES : 5 * SQ_TILE_BYTES) + SQ_WAVES * 4096;
   static_assert(lds <= 160 * 1024, "sq320 LDS");
   static unsigned long long attr_done = 0;
-  tt_lds_opt_in((const void*)sq320_kernel<Tag, HAS_RES>, (int)lds, &attr_done);
+  tt_lds_opt_in((const void*)sq320_kernel<Tag, HAS_RES, HAS_RV>, (int)lds, &attr_done);
   const int ntiles = (p.m + SQ_ROWS - 1) / SQ_ROWS;
-  hipLaunchKernelGGL((sq320_kernel<Tag, HAS_RES>), dim3(ntiles < 256 ? ntiles : 256), dim3(SQ_NT), lds, st, p);
+  hipLaunchKernelGGL((sq320_kernel<Tag, HAS_RES, HAS_RV>), dim3(ntiles < 256 ? ntiles : 256), dim3(SQ_NT), lds, st, p);
 }
 
 template <typename Tag>
