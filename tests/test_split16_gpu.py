@@ -251,3 +251,22 @@ def test_split16_models_pack_their_weights_pre_split(ops):
         assert p_unet._pack_gen == gen + 1 and not isinstance(p_unet.down_blocks[0].resnets[0].spatial_res_block.w1, PreSplitF32)
     finally:
         ops.set_f32_split(True)
+
+
+# ---- the TT_F32 legs of the loop / VAE / pipeline tests, re-run with split-fp16 products (same assertions: every element inside the
+# north-star tolerance).  The VAE decoder's weights are not pre-split (its pack path is its own): its launches convert both operands on the fly.
+def test_split16_fused_loop_matches_oracle_loop(ops):
+    from tests import test_denoise_loop_gpu as L
+    L.test_fused_loop_matches_oracle_loop(True, torch.float32)
+    L.test_fused_loop_matches_oracle_loop(False, torch.float32)
+
+
+def test_split16_vae_decoder_matches_oracle(ops):
+    from tests import test_vae_decoder_gpu as V
+    V.test_decoder_matches_oracle(torch.float32, 1e-4)
+    V.test_decoder_at_the_shipped_widths_matches_oracle(torch.float32, 1e-4)
+
+
+def test_split16_pipeline_call_through_the_native_vae(ops):
+    from tests import test_pipeline_gpu as P
+    P.test_vgl_pipeline_call_produces_frames_through_the_native_vae()
