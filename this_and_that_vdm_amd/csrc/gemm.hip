@@ -485,6 +485,7 @@ extern "C" int tt_gemm(const TtGemmArgs* a, tt_stream_t stream) {
       TT_FAIL(TT_EINVAL, "tt_gemm: presplit operands need TT_F32 with tt_gemm_set_f32_split(1)");
     if (((a->presplit & 1) && a->ln_fold == 1) || ((a->presplit & 2) && a->ln_fold == 2))
       TT_FAIL(TT_EINVAL, "tt_gemm: the LayerNorm statistics cannot be taken from a pre-split operand");
+    if ((a->presplit & 1) && a->mode != 0) TT_FAIL(TT_EINVAL, "tt_gemm: a pre-split A operand is a Linear operand (mode 0)");
   }
   p.gn_out = (char*)a->gn_out; p.ld_gn = a->ld_gn; p.gn_gamma = a->gn_gamma; p.gn_beta = a->gn_beta; p.gn_eps = a->gn_eps; p.gn_silu = a->gn_silu;
   if (p.mode == 1) {

@@ -294,8 +294,10 @@ template <typename Tag, int BM, int BN, int BK, int NST, int WGM, int WGN, int K
 __global__ __launch_bounds__(64 * WGM * WGN, gemm_min_waves(BM, BN, BK / Elem<Tag>::EPC, NST, 64 * WGM * WGN))
 void gemm_kernel(const GemmP p) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
-  constexpr bool SPLIT = KMODE_ >= 8;                  // f32_tag only: KMODE + 8 = the same kernel with split-fp16 products (see `mma`)
-  constexpr int KMODE = SPLIT ? KMODE_ - 8 : KMODE_;
+  constexpr bool SPLIT = (KMODE_ & 8) != 0;            // f32_tag only: KMODE + 8 = the same kernel with split-fp16 products (see `mma`)
+  constexpr bool PRE_B = (KMODE_ & 16) != 0, PRE_A = (KMODE_ & 32) != 0;      // ... + 16 / + 32: the W / A operand arrives pre-split (GemmP.presplit)
+  constexpr int KMODE = KMODE_ & 7;
+  static_assert(SPLIT || (!PRE_A && !PRE_B), "pre-split operands belong to the split variants");
   static_assert(!SPLIT || std::is_same<Tag, f32_tag>::value, "split products are a TT_F32 mode");
   constexpr int MODE = KMODE >= 3 ? 0 : KMODE;         // gather mode
   constexpr int LN = KMODE >= 3 ? KMODE - 2 : 0;       // 0 none, 1 statistics of A rows, 2 of W rows
@@ -557,10 +559,63 @@ void gemm_kernel(const GemmP p) {
     l = make_uint2(l01, l23);
   };
 #if defined(TT_SPLIT_ABL) && (TT_SPLIT_ABL & 1)      // ablation build (timing only, wrong numbers): no conversions at all
-  const bool pre_a = true, pre_b = true;
+  constexpr bool pre_a = true, pre_b = true;
 #else
-  const bool pre_a = SPLIT && (p.presplit & 1), pre_b = SPLIT && (p.presplit & 2);      // launch-uniform
+  constexpr bool pre_a = PRE_A, pre_b = PRE_B;         // compile-time: a branch would cut the block the scheduler interleaves
 #endif
+  // Software pipeline of the split products (TT_SPLIT_PIPE, default on): the MFMAs of chunk pair p are ISSUED during the conversion of the
+  // even chunk of pair p + 1 -- an in-order wave can only overlap its own VALU with its own MFMAs if they alternate in program order (the
+  // ablation of 6.R6: conversions and the two extra MFMAs cost 9 ms each alone and 40 ms together when they run back to back).  The
+  // operands of the pending pair wait in op_* (32 registers for a 64 x 64 wave tile; the pair's temporaries before); the first phase 0 of
+  // a launch issues MFMAs on zero operands (adds nothing), the last pair is flushed after the K loop.
+#ifndef TT_SPLIT_PIPE
+#define TT_SPLIT_PIPE 1
+#endif
+  // block rows of the pending pair issued under the EVEN chunk's conversion; the rest would go under the odd chunk's.  Default: all of
+  // them under the even chunk -- spreading them (1 of 2 rows) keeps the odd chunk's halves in temporaries next to the pending operands
+  // and spills 40-88 bytes per lane on the 64 x 64 wave tiles: 93.4 -> 104.2 ms / step (one call, interleaved).
+#ifndef TT_SPLIT_PIPE_ROWS
+#define TT_SPLIT_PIPE_ROWS 99
+#endif
+  constexpr int PIPE_SPLIT_ROWS = FM > 1 ? (TT_SPLIT_PIPE_ROWS < FM ? TT_SPLIT_PIPE_ROWS : FM) : FM;
+  uint4 op_ah[SPLIT ? FM : 1], op_al[SPLIT ? FM : 1], op_bh[SPLIT ? FN : 1], op_bl[SPLIT ? FN : 1];
+  if constexpr (SPLIT) {
+#pragma unroll
+    for (int i = 0; i < FM; ++i) op_ah[i] = op_al[i] = make_uint4(0, 0, 0, 0);
+#pragma unroll
+    for (int j = 0; j < FN; ++j) op_bh[j] = op_bl[j] = make_uint4(0, 0, 0, 0);
+  }
+  // the same conversion in plain C (14 VALU, no inline asm: every instruction is visible to the scheduler, which is asked to alternate
+  // them with the pending MFMAs); used where the conversion is hidden under MFMAs anyway
+  auto split4c = [&](const raw_u32x4_t& f, bool pre, uint2& h, uint2& l) {
+    if (pre) { h = make_uint2(f.x, f.y); l = make_uint2(f.z, f.w); return; }
+    const f32x2_t v01 = (f32x2_t){__uint_as_float(f.x), __uint_as_float(f.y)}, v23 = (f32x2_t){__uint_as_float(f.z), __uint_as_float(f.w)};
+    const f16x2_t h01 = __builtin_convertvector(v01 * 0.00390625f, f16x2_t), h23 = __builtin_convertvector(v23 * 0.00390625f, f16x2_t);
+    h = make_uint2(__builtin_bit_cast(unsigned, h01), __builtin_bit_cast(unsigned, h23));
+    const f32x2_t r01 = v01 * 8.0f - __builtin_convertvector(h01, f32x2_t) * 2048.0f, r23 = v23 * 8.0f - __builtin_convertvector(h23, f32x2_t) * 2048.0f;
+    l = make_uint2(__builtin_bit_cast(unsigned, __builtin_convertvector(r01, f16x2_t)), __builtin_bit_cast(unsigned, __builtin_convertvector(r23, f16x2_t)));
+  };
+  auto issue_pending = [&](auto lo_tag, auto hi_tag) {               // the three MFMA sweeps of the pair whose operands wait in op_*, block rows [LO, HI)
+   constexpr int LO = decltype(lo_tag)::value, HI = decltype(hi_tag)::value;
+   if constexpr (SPLIT) {
+#if !defined(TT_SPLIT_ABL) || !(TT_SPLIT_ABL & 2)
+#pragma unroll
+    for (int i = LO; i < HI; ++i)
+#pragma unroll
+      for (int j = 0; j < FN; ++j) accx[i][j] = Cvt<f16_tag>::mfma32(op_bl[j], op_ah[i], accx[i][j]);
+#endif
+#pragma unroll
+    for (int i = LO; i < HI; ++i)
+#pragma unroll
+      for (int j = 0; j < FN; ++j) acc[i][j] = Cvt<f16_tag>::mfma32(op_bh[j], op_ah[i], acc[i][j]);
+#if !defined(TT_SPLIT_ABL) || !(TT_SPLIT_ABL & 2)
+#pragma unroll
+    for (int i = LO; i < HI; ++i)
+#pragma unroll
+      for (int j = 0; j < FN; ++j) accx[i][j] = Cvt<f16_tag>::mfma32(op_bh[j], op_al[i], accx[i][j]);
+#endif
+   }
+  };
   auto mma = [&](const raw_u32x4_t (&af)[FM], const raw_u32x4_t (&bf)[FN], int phase) {
     if constexpr (LN == 1) {
 #pragma unroll
@@ -573,7 +628,43 @@ void gemm_kernel(const GemmP p) {
         if constexpr (LN_SHIFT) ln_stat_shifted(bf[j], ln_c[j], ln_s[j], ln_q[j]); else ln_stat<Tag>(bf[j], ln_s[j], ln_q[j]);
       }
     }
-    if constexpr (SPLIT) {
+    if constexpr (SPLIT && TT_SPLIT_PIPE) {
+      if (phase == 0) {                      // (constant after unrolling) even chunk: convert it UNDER the MFMAs of the previous pair
+#pragma unroll
+        for (int i = 0; i < FM; ++i) split4c(af[i], pre_a, sp_ah[i], sp_al[i]);
+#pragma unroll
+        for (int j = 0; j < FN; ++j) split4c(bf[j], pre_b, sp_bh[j], sp_bl[j]);
+        issue_pending(std::integral_constant<int, 0>{}, std::integral_constant<int, PIPE_SPLIT_ROWS>{});
+        // ask for MFMA, VALU, VALU, ... (one MFMA holds the matrix pipe for 8 passes; two or three conversions fit under it)
+#pragma unroll
+        for (int g = 0; g < 3 * PIPE_SPLIT_ROWS * FN; ++g) {
+          __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+          __builtin_amdgcn_sched_group_barrier(0x002, 3, 0);
+        }
+      } else {                               // odd chunk: convert (under the rest of the pending MFMAs), combine with the parked even half
+        uint2 th[FM], tl[FM], ubh[FN], ubl[FN];
+        constexpr bool HIDDEN = PIPE_SPLIT_ROWS < FM;          // MFMAs left to hide the conversion under: the plain-C form; else the 10-VALU asm form
+#pragma unroll
+        for (int i = 0; i < FM; ++i) { if constexpr (HIDDEN) split4c(af[i], pre_a, th[i], tl[i]); else split4(af[i], pre_a, th[i], tl[i]); }
+#pragma unroll
+        for (int j = 0; j < FN; ++j) { if constexpr (HIDDEN) split4c(bf[j], pre_b, ubh[j], ubl[j]); else split4(bf[j], pre_b, ubh[j], ubl[j]); }
+        issue_pending(std::integral_constant<int, PIPE_SPLIT_ROWS>{}, std::integral_constant<int, FM>{});
+#pragma unroll
+        for (int g = 0; g < 3 * (FM - PIPE_SPLIT_ROWS) * FN; ++g) {
+          __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+          __builtin_amdgcn_sched_group_barrier(0x002, 3, 0);
+        }
+#pragma unroll
+        for (int i = 0; i < FM; ++i) {
+          op_ah[i] = make_uint4(sp_ah[i].x, sp_ah[i].y, th[i].x, th[i].y); op_al[i] = make_uint4(sp_al[i].x, sp_al[i].y, tl[i].x, tl[i].y);
+        }
+#pragma unroll
+        for (int j = 0; j < FN; ++j) {
+          op_bh[j] = make_uint4(sp_bh[j].x, sp_bh[j].y, ubh[j].x, ubh[j].y); op_bl[j] = make_uint4(sp_bl[j].x, sp_bl[j].y, ubl[j].x, ubl[j].y);
+        }
+      }
+      __builtin_amdgcn_sched_barrier(0);     // conversions and MFMAs stay in front of the next raw fragment read
+    } else if constexpr (SPLIT) {
       if (phase == 0) {                      // (constant after unrolling)
 #pragma unroll
         for (int i = 0; i < FM; ++i) split4(af[i], pre_a, sp_ah[i], sp_al[i]);
@@ -750,6 +841,7 @@ void gemm_kernel(const GemmP p) {
     tile(KT - 1, std::true_type{});
   }
 
+  if constexpr (SPLIT && TT_SPLIT_PIPE) issue_pending(std::integral_constant<int, 0>{}, std::integral_constant<int, FM>{});       // the last chunk pair's MFMAs
   if constexpr (SPLIT) {                               // 2^16 (hi x hi) + 2^5 (cross terms)
 #pragma unroll
     for (int i = 0; i < FM; ++i)
@@ -1456,12 +1548,25 @@ void launch_cfg(GemmP& p, hipStream_t st) {
   fill_fastdivs(p);
   if constexpr (std::is_same<Tag, f32_tag>::value) {
     if (p.f32_split) {                       // tt_gemm_set_f32_split(1): the split-fp16 product variants (KMODE + 8)
-      if (LNOK && p.ln_fold == 1) { launch_mode<Tag, BM, BN, BK, NST, WGM, WGN, 11>(p, st); return; }
-      if (LNOK && p.ln_fold == 2) { launch_mode<Tag, BM, BN, BK, NST, WGM, WGN, 12>(p, st); return; }
-      switch (p.mode) {
+      // KMODE + 8 (split products) + 16 (W pre-split: packed weights) / + 32 (A pre-split: the swapped V^T projection's weights)
+      const int pre = p.presplit & 3;
+      if (LNOK && p.ln_fold == 1) {          // statistics of the A rows: A is never pre-split here (tt_gemm refuses it)
+        if (pre & 2) launch_mode<Tag, BM, BN, BK, NST, WGM, WGN, 11 + 16>(p, st); else launch_mode<Tag, BM, BN, BK, NST, WGM, WGN, 11>(p, st);
+        return;
+      }
+      if (LNOK && p.ln_fold == 2) {          // statistics of the W rows: W is never pre-split here
+        if (pre & 1) launch_mode<Tag, BM, BN, BK, NST, WGM, WGN, 12 + 32>(p, st); else launch_mode<Tag, BM, BN, BK, NST, WGM, WGN, 12>(p, st);
+        return;
+      }
+      switch (p.mode * 4 + pre) {
         case 0: launch_mode<Tag, BM, BN, BK, NST, WGM, WGN, 8>(p, st); break;
-        case 1: launch_mode<Tag, BM, BN, BK, NST, WGM, WGN, 9>(p, st); break;
-        default: launch_mode<Tag, BM, BN, BK, NST, WGM, WGN, 10>(p, st); break;
+        case 1: launch_mode<Tag, BM, BN, BK, NST, WGM, WGN, 8 + 32>(p, st); break;
+        case 2: launch_mode<Tag, BM, BN, BK, NST, WGM, WGN, 8 + 16>(p, st); break;
+        case 3: launch_mode<Tag, BM, BN, BK, NST, WGM, WGN, 8 + 48>(p, st); break;
+        case 4: case 5: launch_mode<Tag, BM, BN, BK, NST, WGM, WGN, 9>(p, st); break;            // (convs: only the weight is ever pre-split)
+        case 6: case 7: launch_mode<Tag, BM, BN, BK, NST, WGM, WGN, 9 + 16>(p, st); break;
+        case 8: case 9: launch_mode<Tag, BM, BN, BK, NST, WGM, WGN, 10>(p, st); break;
+        default: launch_mode<Tag, BM, BN, BK, NST, WGM, WGN, 10 + 16>(p, st); break;
       }
       return;
     }
