@@ -270,3 +270,46 @@ def test_split16_vae_decoder_matches_oracle(ops):
 def test_split16_pipeline_call_through_the_native_vae(ops):
     from tests import test_pipeline_gpu as P
     P.test_vgl_pipeline_call_produces_frames_through_the_native_vae()
+
+
+# ---- tt_attention on fp32 storage follows the same switch (head dimension 64): both products as three fp16 MFMAs on split operands
+@pytest.mark.parametrize("l,heads,d", [(100, 2, 64), (256, 1, 64), (28, 2, 64), (1000, 3, 64), (200, 1, 128)])
+def test_split16_attention_self(ops, l, heads, d):
+    from tests import test_ops_gpu as T
+    T.test_attention_self(ops, torch.float32, l, heads, d)           # same assertion: rtol = atol = 2e-5 against SDPA in fp32
+
+
+def test_split16_attention_other_paths(ops):
+    """cross-attention (spatial / temporal pairing, 1 / 5 / 78 keys: ragged and masked tiles), the online-softmax rescale branch and
+    scores that grow along the keys (lazy reference point, overflow recovery) -- the exact mode's tests, run on the split variant."""
+    from tests import test_ops_gpu as T
+    for s in (1, 5, 78):
+        T.test_attention_cross_spatial_and_temporal(ops, torch.float32, s)
+    T.test_attention_softmax_rescale_branch(ops, torch.float32)
+    for growth in (6.0, 40.0):
+        T.test_attention_scores_growing_along_the_keys(ops, torch.float32, growth)
+    # growth = 400: raw scores reach several hundred, and a split product carries 2^-22 of its magnitude -- an absolute 1e-4 on such a
+    # score, i.e. 1e-4 relative on its probability: finite, on the slow path, inside 2e-4 (the exact-fp32 MFMA holds 2e-5 there)
+    l, d = 640, 64
+    q, k, v = (f32(1, l, d, seed=s) for s in (1, 2, 3))
+    ramp = torch.linspace(0.0, 1.0, l)[:, None]
+    k = k * 0.3 + ramp * 400.0 * q[0, 5:6] / q[0, 5].norm()
+    out = torch.empty(l, d, dtype=torch.float32, device="cuda")
+    ops.attention(q[0].cuda(), k[0].cuda(), v[0].T.contiguous().cuda(), out, nseq=1, lq=l, heads=1, head_dim=d, mask=0, lk=l, k_seq_stride=l, v_seq_stride=l)
+    assert bool(torch.isfinite(out).all())
+    torch.testing.assert_close(out[None].cpu(), T._sdpa(q, k, v, 1), rtol=2e-4, atol=2e-4)
+
+
+def test_split16_attention_is_the_split_variant_and_close_to_the_exact_one(ops):
+    l, heads, d, nseq = 448, 2, 64, 2
+    c = heads * d
+    q, k, v = (f32(nseq, l, c, seed=s, scale=1.5) for s in (1, 2, 3))
+    vt = v.permute(2, 0, 1).reshape(c, nseq * l).contiguous()
+    def run():
+        out = torch.empty(nseq * l, c, dtype=torch.float32, device="cuda")
+        ops.attention(q.reshape(-1, c).cuda(), k.reshape(-1, c).cuda(), vt.cuda(), out, nseq=nseq, lq=l, heads=heads, head_dim=d, mask=0, lk=l,
+                      k_seq_stride=l, v_seq_stride=l)
+        return out
+    got, exact = both(ops, run)
+    assert not torch.equal(got, exact), "identical bits: the split variant did not run"
+    torch.testing.assert_close(got, exact, rtol=1e-5, atol=1e-5)

@@ -107,9 +107,13 @@ __device__ __forceinline__ Bid3 xcd_remap3() {
 // group reads a [4 keys][16 d] block, lane i supplying the address of the 8-byte run (key i >> 2, d 4 (i & 3) ..) and receiving column i,
 // keys 0..3): two such reads give the 8 keys x 1 d a lane holds of an MFMA operand.  Two address registers per lane; tile half, key block
 // and d block are instruction offsets.
-template <typename Tag, int D, int MASK, bool QP = false, bool VR = false>
+// SP (round 6, fp32 storage only): both products as three fp16 MFMAs on split operands (the "split16" mode of tt_gemm, same scales:
+// common.h split_f16x4) -- Q is split once per block, K / V^T fragments and P per tile; the chunk pairs an x16 MFMA needs sit inside the
+// batches of four the loops already read.  Two accumulators per product (hi x hi and the cross terms), combined before the softmax / at the end.
+template <typename Tag, int D, int MASK, bool QP = false, bool VR = false, bool SP = false>
 __global__ __launch_bounds__(256, (D == 64 && Elem<Tag>::ES == 2) ? 2 : 1) void attn_kernel(const AttnP p) {
   static_assert(!VR || (D == 64 && Elem<Tag>::ES == 2 && MASK == 0 && !QP), "row-major V: spatial self-attention, head dimension 64, 16-bit storage");
+  static_assert(!SP || (Elem<Tag>::ES == 4 && !QP && !VR), "split products: the fp32-storage kernel");
   kernarg_touch<sizeof(AttnP)>();
   extern __shared__ __attribute__((aligned(16))) char smem[];
   typedef typename Elem<Tag>::quad_t quad_t;
@@ -295,6 +299,21 @@ __global__ __launch_bounds__(256, (D == 64 && Elem<Tag>::ES == 2) ? 2 : 1) void 
 #pragma unroll
     for (int r = 0; r < 16; ++r) o[i][r] = 0.f;
   float m_run = -1e30f, l_run = 0.f;
+  f32x16_t ox[SP ? DB : 1];                    // SP: cross-term accumulators of O (o holds hi x hi); both are rescaled together
+  uint4 qh[SP ? DS / 2 : 1], ql[SP ? DS / 2 : 1];
+  if constexpr (SP) {
+#pragma unroll
+    for (int i = 0; i < DB; ++i)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) ox[i][r] = 0.f;
+#pragma unroll
+    for (int i = 0; i < DS / 2; ++i) {          // chunk pair (2i, 2i+1) of the query row = the 8 k-slots of one x16 MFMA
+      uint2 h0, l0, h1, l1;
+      split_f16x4(qf[2 * i].x, qf[2 * i].y, qf[2 * i].z, qf[2 * i].w, h0, l0);
+      split_f16x4(qf[2 * i + 1].x, qf[2 * i + 1].y, qf[2 * i + 1].z, qf[2 * i + 1].w, h1, l1);
+      qh[i] = make_uint4(h0.x, h0.y, h1.x, h1.y); ql[i] = make_uint4(l0.x, l0.y, l1.x, l1.y);
+    }
+  }
 
   // K-tile row read by MFMA row i = l31 so that accumulator reg r <-> key 16*hi + r  (see header)
   const int pi = 16 * ((l31 >> 2) & 1) + (l31 & 3) + 4 * (l31 >> 3);
@@ -370,29 +389,51 @@ __global__ __launch_bounds__(256, (D == 64 && Elem<Tag>::ES == 2) ? 2 : 1) void 
       one(std::integral_constant<int, 0>{}); one(std::integral_constant<int, 1>{});
       one(std::integral_constant<int, 2>{}); one(std::integral_constant<int, 3>{});
     };
-    f32x16_t s[2];
+    f32x16_t s[2], sx[SP ? 2 : 1];
 #pragma unroll
     for (int kb = 0; kb < 2; ++kb)
 #pragma unroll
-      for (int r = 0; r < 16; ++r) s[kb][r] = 0.f;
+      for (int r = 0; r < 16; ++r) { s[kb][r] = 0.f; if constexpr (SP) sx[kb][r] = 0.f; }
     read_k(0, fa);
     read_k(1, fb);
 #pragma unroll
     for (int i = 0; i < NBK; ++i) {
       if (i + 1 < NBK) lds_wait<4>(); else lds_wait<0>();
       const raw_u32x4_t (&f)[4] = (i & 1) ? fb : fa;
+      if constexpr (SP) {
+#pragma unroll
+        for (int kb = 0; kb < 2; ++kb) {                       // f[kb], f[kb + 2]: chunks 2i, 2i + 1 of key block kb
+          uint2 h0, l0, h1, l1;
+          split_f16x4(f[kb].x, f[kb].y, f[kb].z, f[kb].w, h0, l0);
+          split_f16x4(f[kb + 2].x, f[kb + 2].y, f[kb + 2].z, f[kb + 2].w, h1, l1);
+          const uint4 kh = make_uint4(h0.x, h0.y, h1.x, h1.y), kl = make_uint4(l0.x, l0.y, l1.x, l1.y);
+          sx[kb] = Cvt<f16_tag>::mfma32(kl, qh[i], sx[kb]);
+          s[kb] = Cvt<f16_tag>::mfma32(kh, qh[i], s[kb]);
+          sx[kb] = Cvt<f16_tag>::mfma32(kh, ql[i], sx[kb]);
+        }
+      } else {
 #pragma unroll
       for (int j = 0; j < 4; ++j)
         s[j & 1] = Cvt<Tag>::mfma32(make_uint4(f[j].x, f[j].y, f[j].z, f[j].w), qf[2 * i + (j >> 1)], s[j & 1]);
+      }
       __builtin_amdgcn_sched_barrier(0);                       // the MFMAs read the batch before it is re-filled
       if (i + 2 < NBK) { if (i & 1) read_k(i + 2, fb); else read_k(i + 2, fa); }
     }
     if constexpr (VR) {
       read_vr(std::integral_constant<int, 0>{}, ga);
       read_vr(std::integral_constant<int, 1>{}, gb);
-    } else {
+    } else if constexpr (!SP) {
       read_v(0, fa);
       if constexpr (NBV > 1) read_v(1, fb);
+    }
+    // (SP requests its first V^T batches AFTER the softmax: at its register pressure -- 256 VGPRs + 160 AGPRs -- fragments that stay live
+    // across the softmax get copied to accumulation registers right behind the raw read, i.e. before their data has landed: the hazard of
+    // cdna guide 5.7 item 1, seen as a whole batch of keys missing from O.)
+    if constexpr (SP) {                                          // 2^16 (hi x hi) + 2^5 (cross terms)
+#pragma unroll
+      for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) s[kb][r] = fmaf(sx[kb][r], 32.0f, s[kb][r] * 65536.0f);
     }
     // ---- mask + online softmax (lane: one query, keys j0 + kb*32 + hi*16 + r).  Raw scores stay unscaled: the
     // 1/sqrt(d)*log2(e) factor c is folded into the exponent, p = exp2(s*c - m*c), one FMA per score.
@@ -415,6 +456,7 @@ __global__ __launch_bounds__(256, (D == 64 && Elem<Tag>::ES == 2) ? 2 : 1) void 
     constexpr float PSUM_OK = 16384.0f;
     float psum = 0.f;
     uint4 pf[2][PH];
+    uint2 ph2[SP ? 2 : 1][SP ? PH : 1], pl2[SP ? 2 : 1][SP ? PH : 1];       // SP: the split halves of every P chunk
     auto exponentiate = [&](float m_ref) {
       psum = 0.f;
 #pragma unroll
@@ -442,11 +484,20 @@ __global__ __launch_bounds__(256, (D == 64 && Elem<Tag>::ES == 2) ? 2 : 1) void 
 #pragma unroll
       for (int i = 0; i < DB; ++i)
 #pragma unroll
-        for (int r = 0; r < 16; ++r) o[i][r] *= alpha;
+        for (int r = 0; r < 16; ++r) { o[i][r] *= alpha; if constexpr (SP) ox[i][r] *= alpha; }
       m_run = m_new;
       exponentiate(m_run);
     }
     l_run += psum;
+    if constexpr (SP) {                                          // split the FINAL probabilities once (the optimistic pass may have produced inf)
+#pragma unroll
+      for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+        for (int h = 0; h < PH; ++h) split_f16x4(pf[kb][h].x, pf[kb][h].y, pf[kb][h].z, pf[kb][h].w, ph2[kb][h], pl2[kb][h]);
+      __builtin_amdgcn_sched_barrier(0);
+      read_v(0, fa);
+      if constexpr (NBV > 1) read_v(1, fb);
+    }
     // ---- O^T += Vt_tile * P^T : k-slot (hi, e) of read k = kb*PH + h is key kb*32 + 16*hi + EPC*h + e
     if constexpr (VR) {                                        // (NBV = 2: both batches were requested before the softmax)
 #pragma unroll
@@ -465,10 +516,27 @@ __global__ __launch_bounds__(256, (D == 64 && Elem<Tag>::ES == 2) ? 2 : 1) void 
     for (int i = 0; i < NBV; ++i) {
       if (i + 1 < NBV) lds_wait<4>(); else lds_wait<0>();
       const raw_u32x4_t (&f)[4] = (i & 1) ? fb : fa;
+      if constexpr (SP) {
+        const int k0 = 2 * (i % PH), kb = k0 / PH, h0 = k0 % PH;         // f[jd], f[jd + 2]: key chunks k0, k0 + 1 of d block 2 (i / PH) + jd
+        const uint4 ph = make_uint4(ph2[kb][h0].x, ph2[kb][h0].y, ph2[kb][h0 + 1].x, ph2[kb][h0 + 1].y);
+        const uint4 pl = make_uint4(pl2[kb][h0].x, pl2[kb][h0].y, pl2[kb][h0 + 1].x, pl2[kb][h0 + 1].y);
+#pragma unroll
+        for (int jd = 0; jd < 2; ++jd) {
+          const int db = 2 * (i / PH) + jd;
+          uint2 vh0, vl0, vh1, vl1;
+          split_f16x4(f[jd].x, f[jd].y, f[jd].z, f[jd].w, vh0, vl0);
+          split_f16x4(f[jd + 2].x, f[jd + 2].y, f[jd + 2].z, f[jd + 2].w, vh1, vl1);
+          const uint4 vh = make_uint4(vh0.x, vh0.y, vh1.x, vh1.y), vl = make_uint4(vl0.x, vl0.y, vl1.x, vl1.y);
+          ox[db] = Cvt<f16_tag>::mfma32(vl, ph, ox[db]);
+          o[db] = Cvt<f16_tag>::mfma32(vh, ph, o[db]);
+          ox[db] = Cvt<f16_tag>::mfma32(vh, pl, ox[db]);
+        }
+      } else {
 #pragma unroll
       for (int j = 0; j < 4; ++j) {
         const int db = 2 * (i / PH) + (j & 1), k = 2 * (i % PH) + (j >> 1);
         o[db] = Cvt<Tag>::mfma32(make_uint4(f[j].x, f[j].y, f[j].z, f[j].w), pf[k / PH][k % PH], o[db]);
+      }
       }
       __builtin_amdgcn_sched_barrier(0);
       if (i + 2 < NBV) { if (i & 1) read_v(i + 2, fb); else read_v(i + 2, fa); }
@@ -493,6 +561,12 @@ __global__ __launch_bounds__(256, (D == 64 && Elem<Tag>::ES == 2) ? 2 : 1) void 
   // ---- finalize: lane holds query l31, d = db*32 + 8g + 4hi + {0..3}.  Stored directly an instruction would write 16
   // bytes to each of 32 rows; instead the wave's 32 x D outputs go through a private LDS strip (the K/V ring is free
   // now) and leave as full rows: 8 (D = 64) or 16 lanes cover one row's D*2 contiguous bytes.
+  if constexpr (SP) {
+#pragma unroll
+    for (int i = 0; i < DB; ++i)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) o[i][r] = fmaf(ox[i][r], 32.0f, o[i][r] * 65536.0f);
+  }
   float l_tot = l_run + __shfl_xor(l_run, 32);
   const float inv = l_tot > 0.f ? 1.0f / l_tot : 0.f;
   __syncthreads();                                     // every wave is done with the K / V tiles
@@ -770,11 +844,19 @@ template <typename Tag, int D, int MASK>
 void launch_attn_m(const AttnP& p, hipStream_t st) {
   constexpr size_t lds = 2 * (KB * D * Elem<Tag>::ES + D * KB * Elem<Tag>::ES);
   static_assert(lds <= 160 * 1024, "attention K/V ring exceeds the LDS");
-  static unsigned long long attr_done = 0;
-  tt_lds_opt_in((const void*)attn_kernel<Tag, D, MASK>, (int)lds, &attr_done);
   // mask 2: one block per (query residue class, QB queries of that class)
   const int cls = MASK == 2 ? p.ctx_batches : 1;
   const dim3 grid(cls * ((((p.lq + cls - 1) / cls) + QB - 1) / QB), p.heads, p.nseq);
+  if constexpr (Elem<Tag>::ES == 4 && D == 64) {      // (head dimension 128 keeps the exact-fp32 MFMA: its split variant spills 1 KiB per lane)
+    if (tt_internal_f32_split()) {             // TT_F32 "split16": the split-product variant of the same kernel
+      static unsigned long long attr_done_sp = 0;
+      tt_lds_opt_in((const void*)attn_kernel<Tag, D, MASK, false, false, true>, (int)lds, &attr_done_sp);
+      hipLaunchKernelGGL((attn_kernel<Tag, D, MASK, false, false, true>), grid, dim3(256), lds, st, p);
+      return;
+    }
+  }
+  static unsigned long long attr_done = 0;
+  tt_lds_opt_in((const void*)attn_kernel<Tag, D, MASK>, (int)lds, &attr_done);
   hipLaunchKernelGGL((attn_kernel<Tag, D, MASK>), grid, dim3(256), lds, st, p);
 }
 // cross-attention with the query projection fused in (D = 64, 16-bit): LDS = the 3 x 24 KiB projection ring (the K / V^T ring reuses it)

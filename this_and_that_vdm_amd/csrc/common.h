@@ -282,3 +282,21 @@ template <int BYTES> __device__ __forceinline__ void kernarg_touch() {
 }
 
 static inline int ceil_div(long a, long b) { return (int)((a + b - 1) / b); }
+
+// ---------------------------------------------------------------- split-fp16 operands (TT_F32 "split16", tt_gemm_set_f32_split)
+// x = 2^8 h + 2^-3 l with h = fp16(x 2^-8), l = fp16((x - 2^8 h) 2^3) = fp16(8 x - 2048 h): 4 fp32 values -> two fp16 pairs each (10 VALU;
+// the fp16 operand of v_fma_mix is widened by the instruction, the fused result is rounded once).  See gemm_kernel.h (`mma`) for the scales.
+int tt_internal_f32_split();         // gemm.hip: the process-wide switch (attention.hip follows it)
+__device__ __forceinline__ void split_f16x4(unsigned x0, unsigned x1, unsigned x2, unsigned x3, uint2& h, uint2& l) {
+  const f32x2_t v01 = (f32x2_t){__uint_as_float(x0), __uint_as_float(x1)}, v23 = (f32x2_t){__uint_as_float(x2), __uint_as_float(x3)};
+  const f16x2_t h01 = __builtin_convertvector(v01 * 0.00390625f, f16x2_t), h23 = __builtin_convertvector(v23 * 0.00390625f, f16x2_t);
+  h = make_uint2(__builtin_bit_cast(unsigned, h01), __builtin_bit_cast(unsigned, h23));
+  const f32x2_t e01 = v01 * 8.0f, e23 = v23 * 8.0f;
+  const float m2048 = -2048.0f;
+  unsigned l01, l23;
+  asm("v_fma_mixlo_f16 %0, %1, %2, %3 op_sel_hi:[1,0,0]" : "=v"(l01) : "v"(h.x), "v"(m2048), "v"(e01.x));
+  asm("v_fma_mixhi_f16 %0, %1, %2, %3 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "+v"(l01) : "v"(h.x), "v"(m2048), "v"(e01.y));
+  asm("v_fma_mixlo_f16 %0, %1, %2, %3 op_sel_hi:[1,0,0]" : "=v"(l23) : "v"(h.y), "v"(m2048), "v"(e23.x));
+  asm("v_fma_mixhi_f16 %0, %1, %2, %3 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "+v"(l23) : "v"(h.y), "v"(m2048), "v"(e23.y));
+  l = make_uint2(l01, l23);
+}

@@ -226,6 +226,7 @@ static int f32_split() {
   if (g_f32_split < 0) { const char* e = getenv("TT_F32_SPLIT"); g_f32_split = e && atoi(e) ? 1 : 0; }
   return g_f32_split;
 }
+int tt_internal_f32_split() { return f32_split(); }
 static int g_w320 = -1;
 extern "C" int tt_gemm_set_big_tile(int32_t on) {
   // internal: bit 0 the 256 x 320 kernel, bit 1 its 128 x 320 variant, bit 2: that one for conv3x3 only, bit 3: its split-K route
