@@ -339,6 +339,21 @@ static Plan plan_for(const TtGemmArgs* a) {
     // any conversion 74.8; with one MFMA per product block instead of three 75.1; with neither 65.9 -- conversions and the two extra MFMAs
     // cost ~9 ms each on their own and ~40 ms together: inside one wave they run back to back (the fragment consumers are pinned by
     // sched_barrier: the raw-read hazard of gemm_kernel.h), so the matrix pipe idles while a wave converts.
+    if (f32_split()) {
+      // split16, few tiles and a long K (the coarsest level's convs: 784 rows x 1280 x 11 520 = 70 tiles of 128 x 128, 360 K steps of 32): the
+      // 64 x 64 tiles ran them at ~100 TFLOP/s (260 workgroups, one round, VALU-bound wave tiles).  The K loop split over S workgroups per
+      // 128 x 128 tile, fp32 slabs summed in a fixed order by the reduction pass (the 16-bit modes' plan for these shapes; bit-reproducible).
+      static int sk = -1;
+      if (sk < 0) { const char* e = getenv("TT_F32_SPLITK"); sk = e ? atoi(e) : 1; }
+      const long b128 = (long)ceil_div(a->m, 128) * ceil_div(a->n, 128);
+      const long kt = (long)(a->mode == 1 ? 9 : (a->mode == 2 ? 3 : 1)) * (a->k0 + a->k1) / 32;
+      if (sk && !a->geglu && !a->ln_fold && !a->out_col_hw && b128 < split_min && kt >= 64) {
+        long sp = 448 / b128;
+        if (sp > kt / 16) sp = kt / 16;
+        if (sp > 16) sp = 16;
+        if (sp >= 2) return Plan{0, (int)sp};
+      }
+    }
     return Plan{plan_f32(a->m, a->n, f32_split() ? split_min : 256), 1};
   }
   const int taps = a->mode == 1 ? 9 : (a->mode == 2 ? 3 : 1);
@@ -352,6 +367,12 @@ static Plan plan_for(const TtGemmArgs* a) {
     g_forced_cfg = keep;
   }
   return pl;
+}
+
+// the plan of a problem whose split plan cannot be served (no / too small a workspace)
+static Plan unsplit_plan(const TtGemmArgs* a) {
+  if (a->dtype == TT_F32) return Plan{plan_f32(a->m, a->n, 256), 1};
+  return Plan{make_plan(a->m, a->n, 0, false, !(a->residual || a->blend || a->rowvec)).cfg, 1};
 }
 
 extern "C" int tt_gemm_plan(const TtGemmArgs* a, int32_t cfg[7]) {
@@ -377,7 +398,7 @@ extern "C" int tt_gemm_plan(const TtGemmArgs* a, int32_t cfg[7]) {
   Plan pl = plan_for(a);
   if (pl.splitk > 1 && (!a->ws || (size_t)a->ws_bytes < (size_t)pl.splitk * a->m * a->n * sizeof(float) ||
                         (long)pl.splitk * a->m * a->n * 4 >= (1L << 31)))
-    pl = Plan{make_plan(a->m, a->n, 0, false, !(a->residual || a->blend || a->rowvec)).cfg, 1};
+    pl = unsplit_plan(a);
   const TileCfg& t = a->dtype == TT_F32 ? kCfgsF32[pl.cfg] : kCfgs[pl.cfg];
   cfg[0] = t.bm; cfg[1] = t.bn; cfg[2] = t.bk; cfg[3] = t.nst; cfg[4] = t.wgm; cfg[5] = t.wgn; cfg[6] = pl.splitk;
   return TT_OK;
@@ -548,9 +569,9 @@ extern "C" int tt_gemm(const TtGemmArgs* a, tt_stream_t stream) {
   }
   Plan pl = plan_for(a);
   if (pl.splitk > 1 && (!a->ws || (size_t)a->ws_bytes < (size_t)pl.splitk * a->m * a->n * sizeof(float)))
-    pl = Plan{make_plan(a->m, a->n, 0, false, !(a->residual || a->blend || a->rowvec)).cfg, 1};            // no workspace: un-split plan (still correct)
+    pl = unsplit_plan(a);            // no workspace: un-split plan (still correct)
   if (pl.splitk > 1 && (long)pl.splitk * a->m * a->n * 4 >= (1L << 31))
-    pl = Plan{make_plan(a->m, a->n, 0, false, !(a->residual || a->blend || a->rowvec)).cfg, 1};            // slabs beyond the 32-bit offsets: un-split plan
+    pl = unsplit_plan(a);            // slabs beyond the 32-bit offsets: un-split plan
   p.splitk = pl.splitk;
   p.group_m_override = group_m_override(); p.group_m = 1;
   p.ws = (float*)a->ws;
