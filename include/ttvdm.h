@@ -178,7 +178,9 @@ int tt_gemm_set_big_tile(int32_t on);
  *      accumulators -- max(2^-22 |x|, 2^-28) per operand, operands up to |x| < 2^24 (beyond that the hi part overflows to inf),
  *      3 x 8 passes per 32 x 32 x 16 block instead of 8 x 16.  Storage, epilogues,
  *      LayerNorm statistics and accumulation stay fp32; the mode meets the north-star tolerance (rtol 1e-3 / atol 1e-4 against the
- *      reference's CPU fp32 forward, svd/unet_spatio_temporal_condition.py:363-536) at about a third of the exact mode's step time. */
+ *      reference's CPU fp32 forward, svd/unet_spatio_temporal_condition.py:363-536) at about half of the exact mode's step time.
+ *      tt_attention on fp32 storage (head_dim 64) follows the same switch; few-tile long-K problems take a split-K plan in this mode
+ *      (fp32 slabs in the tt_gemm_ws_bytes workspace, summed in a fixed order). */
 int tt_gemm_set_f32_split(int32_t on);
 
 /* ------------------------------------------------------------------------------------------------
