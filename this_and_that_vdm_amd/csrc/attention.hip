@@ -114,6 +114,10 @@ template <typename Tag, int D, int MASK, bool QP = false, bool VR = false, bool 
 __global__ __launch_bounds__(256, (D == 64 && Elem<Tag>::ES == 2) ? 2 : 1) void attn_kernel(const AttnP p) {
   static_assert(!VR || (D == 64 && Elem<Tag>::ES == 2 && MASK == 0 && !QP), "row-major V: spatial self-attention, head dimension 64, 16-bit storage");
   static_assert(!SP || (Elem<Tag>::ES == 4 && !QP && !VR), "split products: the fp32-storage kernel");
+  // (round 6 probe, removed: delaying the workgroup in the odd wave slot of a SIMD by 0.25-1 us so that one of the two resident workgroups
+  // multiplies while the other exponentiates -- 138.3 / 2023 us -> 136.9-138.6 / 2005-2042 us at 1 792 / 7 168 keys: nothing.  Per tile a wave has
+  // 16 MFMAs (512 matrix-pipe clocks) and 112 VALU of which 32 are quarter-rate exponentials (~830 issue clocks): two waves per SIMD are VALU-bound
+  // at 61 % matrix-pipe use, the kernel sits at 47 %.)
   kernarg_touch<sizeof(AttnP)>();
   extern __shared__ __attribute__((aligned(16))) char smem[];
   typedef typename Elem<Tag>::quad_t quad_t;
