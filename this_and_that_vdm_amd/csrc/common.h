@@ -201,6 +201,23 @@ __device__ __forceinline__ f32pk_t gelu_sig_pk(f32pk_t x) {
   return x * (f32pk_t){__builtin_amdgcn_rcpf(d.x), __builtin_amdgcn_rcpf(d.y)};
 }
 
+// GELU without transcendentals (round 6; bf16 storage in the persistent GEGLU kernel only): Phi(x) ~ 0.5 + xc P(xc^2), xc = clamp(x, +-3.75),
+// P of degree 6 in x^2 (least-squares / Lawson fit on Chebyshev nodes: max |dPhi| = 5.6e-5, max |x dPhi| = 3.9e-4 over |x| <= 12 in fp32
+// arithmetic -- an order below bf16's 2^-9 output rounding wherever the output exceeds 0.1, absolute 4e-4 at most elsewhere; beyond the clamp
+// Phi stays at 0.99997 / 3.2e-5, a relative 3e-5 on gelu(x) ~ x).  v_exp_f32 and v_rcp_f32 issue at a quarter of the VALU rate: the sigmoid
+// form above costs 4 packed-equivalent VALU + 2 transcendentals per value = 48 clocks, this one 9 packed instructions + 2 clamps per PAIR = 22.
+__device__ __forceinline__ f32pk_t gelu_poly_pk(f32pk_t x) {
+  const f32pk_t xc = {__builtin_amdgcn_fmed3f(x.x, -3.75f, 3.75f), __builtin_amdgcn_fmed3f(x.y, -3.75f, 3.75f)};
+  const f32pk_t t = xc * xc;
+  f32pk_t q = t * 3.9124383732769275e-08f + -2.3762543150951387e-06f;
+  q = q * t + 6.234781903913245e-05f;
+  q = q * t + -0.0009441798320040107f;
+  q = q * t + 0.009362553246319294f;
+  q = q * t + -0.06578987091779709f;
+  q = q * t + 0.39870646595954895f;
+  return x * (xc * q + 0.5f);
+}
+
 // ---------------------------------------------------------------- LDS tile staging (global -> LDS DMA)
 // A tile is ROWS x (CPR chunks of 16 B).  The LDS image is lane-linear (DMA requirement): slot s holds
 // the chunk (row = s / CPR, chunk' = s % CPR); the data stored there is source chunk  c = c' ^ swz(row),

@@ -335,8 +335,10 @@ __global__ __launch_bounds__(512, 2) void gemm_pp_kernel(const GemmP p) {
               const f32pk_t g23 = (f32pk_t){acc[i][j][(2 * tt + 1) * 4 + 2], acc[i][j][(2 * tt + 1) * 4 + 3]} * r2 + (f32pk_t){bg.z, bg.w};
 #ifdef TT_GELU_ERF_AS          // A/B build only (make variant): the Abramowitz-Stegun erf form of rounds 3-4
 #define TT_PP_GELU gelu_erf_pk
-#else
+#elif defined(TT_GELU_SIG)    // A/B build only: the sigmoid form of round 5 for every storage type
 #define TT_PP_GELU gelu_sig_pk
+#else                          // bf16 storage: the transcendental-free polynomial (its error sits below bf16's output rounding); fp16: the sigmoid form
+#define TT_PP_GELU(x) (std::is_same<Tag, bf16_tag>::value ? gelu_poly_pk(x) : gelu_sig_pk(x))
 #endif
               const f32pk_t v01 = ((f32pk_t){acc[i][j][(2 * tt) * 4], acc[i][j][(2 * tt) * 4 + 1]} * r2 + (f32pk_t){bv.x, bv.y}) * TT_PP_GELU(g01);
               const f32pk_t v23 = ((f32pk_t){acc[i][j][(2 * tt) * 4 + 2], acc[i][j][(2 * tt) * 4 + 3]} * r2 + (f32pk_t){bv.z, bv.w}) * TT_PP_GELU(g23);
