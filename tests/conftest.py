@@ -1,6 +1,11 @@
 import os
 import sys
 
+# Idle OpenMP workers SLEEP instead of spinning (must be set before libgomp is loaded, i.e. before the first `import torch`): by the time the
+# oracle tests run, the process holds two OpenMP runtimes and two OpenBLAS pools (torch, scipy, transformers), and spinning workers of one
+# starve the other on the build container's 8 cores -- the tiny-model oracle tests took 60-100 s each instead of 3 s (CPU suite 6 min vs 3).
+os.environ.setdefault("OMP_WAIT_POLICY", "PASSIVE")
+
 import pytest
 
 REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
