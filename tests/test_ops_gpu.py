@@ -355,6 +355,32 @@ def test_attention_scores_growing_along_the_keys(ops, dtype, growth):
     close(out[None], _sdpa(q, k, v, 1), dtype)
 
 
+@pytest.mark.parametrize("dtype", DTYPES16)
+@pytest.mark.parametrize("l,growth", [(128, 0.0), (192, 0.0), (320, 0.0), (640, 6.0), (640, 40.0), (640, 400.0), (704, 400.0)])
+def test_attention_pipelined_self_attention(ops, dtype, l, growth, monkeypatch):
+    """attn_pipe_kernel (v_rows, whole 64-key tiles, >= 2 tiles): the softmax of tile t runs beside O += V(t-1) P(t-1), P is carried across
+    the loop.  Two / three / five tiles (first-iteration, tail and epilogue paths), even and odd tile counts, a ragged query block, and scores
+    growing along the keys (the slow path rescales O AFTER the iteration's PV).  Must match fp32 SDPA and -- same MFMA operands and
+    summation order -- the un-pipelined kernel bit for bit (same process: the switch is read once per process, so that side runs the V^T route)."""
+    d, heads, nseq = 64, 2, 2
+    c = heads * d
+    q, k, v = (rnd(nseq, l, c, dtype=torch.float32, seed=s) for s in (1, 2, 3))
+    if growth:
+        ramp = torch.linspace(0.0, 1.0, l)[None, :, None]
+        k = k * 0.3 + ramp * growth * q[:, 5:6] / q[:, 5:6].norm(dim=-1, keepdim=True) / heads ** 0.5
+    q, k, v = q.to(dtype), k.to(dtype), v.to(dtype)
+    qkv = torch.cat([q, k, v], dim=2).reshape(nseq * l, 3 * c).cuda()
+    vt = v.permute(2, 0, 1).reshape(c, nseq * l).contiguous()
+    kw = dict(nseq=nseq, lq=l, heads=heads, head_dim=d, mask=0, lk=l, k_seq_stride=l, v_seq_stride=l)
+    out_t = torch.empty(nseq * l, c, dtype=dtype, device="cuda")
+    ops.attention(qkv[:, :c], qkv[:, c:2 * c], vt.cuda(), out_t, **kw)
+    out_r = torch.empty(nseq * l, c, dtype=dtype, device="cuda")
+    ops.attention(qkv[:, :c], qkv[:, c:2 * c], qkv[:, 2 * c:], out_r, v_rows=True, **kw)
+    assert bool(torch.isfinite(out_r.float()).all())
+    close(out_r.view(nseq, l, c), _sdpa(q, k, v, heads), dtype)
+    assert torch.equal(out_r, out_t), "the pipelined kernel must give the un-pipelined kernel's output bit for bit"
+
+
 @pytest.mark.parametrize("dtype", DTYPES)
 @pytest.mark.parametrize("s", [1, 5, 78])
 def test_attention_cross_spatial_and_temporal(ops, dtype, s):

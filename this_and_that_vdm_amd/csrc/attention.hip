@@ -12,6 +12,10 @@
 #include <type_traits>
 #include "common.h"
 
+#ifndef TT_ATTN_PIPE_SGB
+#define TT_ATTN_PIPE_SGB 1
+#endif
+
 namespace {
 
 struct AttnP {
@@ -597,6 +601,259 @@ __global__ __launch_bounds__(256, (D == 64 && Elem<Tag>::ES == 2) ? 2 : 1) void 
 }
 
 // ---------------------------------------------------------------------------------------------
+// Spatial self-attention, software-pipelined ACROSS key tiles (round 6; VR operand layout, D = 64, 16-bit storage, lk a multiple of 64).
+// attn_kernel runs a tile as QK^T -> softmax -> PV inside one wave, so a wave alternates ~512 matrix-pipe clocks with ~530 VALU issue clocks and
+// the two waves of a SIMD (two resident workgroups) were measured to add up rather than overlap (matrix pipe 47 % busy).  Here iteration t of a
+// wave runs S(t) = K(t) Q^T and then the softmax of tile t BESIDE O += V(t-1) P(t-1): matrix and vector instructions alternate in program order,
+// which is the only overlap an in-order wave has by construction.  P is carried across the loop (the B operand of the NEXT iteration's PV);
+// K(t+1) and V(t) are requested in iteration t, one iteration before they are read.  Lazy softmax reference exactly as in attn_kernel (the slow
+// path rescales O after the iteration's PV: O and P(t-1) are both relative to the old reference at that point).  Same MFMA operands and summation
+// order as attn_kernel: bit-identical outputs (tests/test_ops_gpu.py).  (A deeper version -- S(t+1) beside the softmax as well, two S and two P
+// register sets alternating with the tile parity -- compiled to 64-register tuple copies per tile and 236-260 bytes of scratch per lane at two
+// waves per SIMD, and to accumulator-file copies of every score at one: not kept.)
+template <typename Tag>
+__global__ __launch_bounds__(256, 2) void attn_pipe_kernel(const AttnP p) {
+  static_assert(Elem<Tag>::ES == 2, "16-bit storage");
+  kernarg_touch<sizeof(AttnP)>();
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  typedef typename Elem<Tag>::quad_t quad_t;
+  constexpr int D = 64, ES = 2, EPC = 8, CPR = 8;            // 128-byte tile rows (K: [64 keys][64 d]; V the same, keys as rows)
+  constexpr int K_BYTES = KB * D * ES, V_BYTES = KB * D * ES, PT = (KB * CPR) / 256;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int l31 = lane & 31, hi = lane >> 5;
+  const Bid3 blk = xcd_remap3<false>();
+  const int head = blk.y, seq = blk.z;
+  const int kbase = seq * p.k_seq_stride, vbase = seq * p.v_seq_stride;
+  const int nt = p.lk / KB;
+
+  const int qrow = blk.x * QB + wid * 32 + l31;
+  const bool qok = qrow < p.lq;
+  uint4 qf[4];
+  {
+    const char* qp = p.q + (((long)seq * p.lq + (qok ? qrow : 0)) * p.ldq + head * D) * ES;
+#pragma unroll
+    for (int ds = 0; ds < 4; ++ds) qf[ds] = qok ? *(const uint4*)(qp + (ds * 2 + hi) * 16) : make_uint4(0, 0, 0, 0);
+  }
+  const __amdgpu_buffer_rsrc_t rk = __builtin_amdgcn_make_buffer_rsrc((void*)p.k, 0, p.k_bytes, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rv = __builtin_amdgcn_make_buffer_rsrc((void*)p.vt, 0, p.vt_bytes, 0x00020000);
+  int kvo[PT], vvo[PT];
+#pragma unroll
+  for (int i = 0; i < PT; ++i) {
+    const int slot = i * 256 + tid;
+    const int r = slot / CPR, c = (slot % CPR) ^ tile_swz<CPR>(r);
+    kvo[i] = (int)((((long)kbase + r) * p.ldk + head * D + c * EPC) * ES);
+    vvo[i] = (int)((((long)vbase + r) * p.ldvt + head * D + c * EPC) * ES);
+  }
+  auto stage_k = [&](int buf, int tile) {
+    char* l_ = smem + buf * K_BYTES + wid * 1024;
+    const int soff = __builtin_amdgcn_readfirstlane((int)((long)tile * KB * p.ldk * ES));
+#pragma unroll
+    for (int i = 0; i < PT; ++i)
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(rk, (__attribute__((address_space(3))) void*)(l_ + i * 4096), 16, kvo[i], soff, 0, 0);
+  };
+  auto stage_v = [&](int buf, int tile) {
+    char* l_ = smem + 2 * K_BYTES + buf * V_BYTES + wid * 1024;
+    const int soff = __builtin_amdgcn_readfirstlane((int)((long)tile * KB * p.ldvt * ES));
+#pragma unroll
+    for (int i = 0; i < PT; ++i)
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(rv, (__attribute__((address_space(3))) void*)(l_ + i * 4096), 16, vvo[i], soff, 0, 0);
+  };
+
+  f32x16_t o[2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) o[i][r] = 0.f;
+  float m_run = -1e30f, l_run = 0.f;
+  uint4 P[4];                                                // probabilities of the PREVIOUS tile, chunk 2 kb + h (the B operand of its PV)
+#pragma unroll
+  for (int c = 0; c < 4; ++c) P[c] = make_uint4(0, 0, 0, 0);
+
+  const int pi = 16 * ((l31 >> 2) & 1) + (l31 & 3) + 4 * (l31 >> 3);          // (attn_kernel: accumulator register r <-> key 16 hi + r)
+  const unsigned lds_base = lds_addr(smem);
+  unsigned kaddr[4];                                         // key block 0; key block 1 is + 32 rows = + 4096 bytes (the swizzle only sees row bits 1-3)
+#pragma unroll
+  for (int ds = 0; ds < 4; ++ds) kaddr[ds] = lds_base + tile_off<CPR>(pi, ds * 2 + hi);
+  unsigned vr_addr[2];
+  {
+    const int gi = lane & 15, gg = lane >> 4, r2 = gi >> 2;
+    const int base = ((gg & 1) * 2 + ((gi & 3) >> 1)) ^ ((gi >> 3) & 1);
+#pragma unroll
+    for (int half = 0; half < 2; ++half)
+      vr_addr[half] = lds_base + (gg >> 1) * 2048 + r2 * 128 + half * 512 + ((base ^ (half << 1)) << 4) + (gi & 1) * 8;
+  }
+  constexpr float PSUM_OK = 16384.0f;
+
+  auto tile = [&](int t, auto buf_tag, auto pv_tag) {
+    constexpr int BUF = decltype(buf_tag)::value;
+    constexpr bool HAS_PV = decltype(pv_tag)::value;
+    constexpr int KOFF = BUF * K_BYTES, VOFF = 2 * K_BYTES + (BUF ^ 1) * V_BYTES;            // K(t) in its own parity's buffer, V(t-1) in the other's
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");          // this wave's pieces of K(t) and V(t-1) have landed ...
+    __syncthreads();                                           // ... and everybody's; K buffer BUF ^ 1 and V buffer BUF are free (read in iteration t-1)
+    if (t + 1 < nt) stage_k(BUF ^ 1, t + 1);
+    stage_v(BUF, t);
+    // Matrix work of the iteration, in batches of two MFMAs.  S(t) = K(t) Q^T key block by key block (each a chain of four MFMAs on one
+    // accumulator: with the lazy reference a score can be exponentiated as soon as ITS sum over d is complete, no row maximum is waited for):
+    //   K0, K1 = key block 0, head-dimension chunks {0, 1}, {2, 3}      (alone)
+    //   K2, K3 = key block 1                                           beside softmax chunks 0, 1 (key block 0)
+    //   M0..M3 = O += V(t-1) P(t-1), key chunk M                        beside softmax chunks 2, 3 (key block 1), half a chunk per batch
+    // Operand reads: two batches in flight (x, y), raw, counted waits.
+    raw_u32x4_t x[2], y[2];                                    // a V batch is four 8-byte transposing reads = the same 8 registers
+    auto request_k = [&](auto n_tag, raw_u32x4_t (&f)[2]) {    // batch n: key block n >> 1 (+ 32 rows = + 4096 bytes, same swizzle), chunks 2 (n & 1) + {0, 1}
+      constexpr int N = decltype(n_tag)::value;
+      f[0] = lds_read16_raw_off<KOFF + (N >> 1) * 4096>(kaddr[2 * (N & 1)]);
+      f[1] = lds_read16_raw_off<KOFF + (N >> 1) * 4096>(kaddr[2 * (N & 1) + 1]);
+    };
+    auto request_v = [&](auto m_tag, raw_u32x4_t (&f)[2]) {    // V^T fragments (d block db, key chunk k = M): attn_kernel's read_vr
+      constexpr int M = decltype(m_tag)::value;
+      constexpr int kb = M / 2, h = M % 2;
+      auto one = [&](auto db_tag) {
+        constexpr int db = decltype(db_tag)::value;
+        constexpr int off = VOFF + kb * 4096 + h * 1024 + ((db ^ h) << 6);
+        const raw_u32x2_t lo = lds_read8_tr_off<off>(vr_addr[0]), hi2 = lds_read8_tr_off<off>(vr_addr[1]);
+        f[db] = (raw_u32x4_t){lo.x, lo.y, hi2.x, hi2.y};
+      };
+      one(std::integral_constant<int, 0>{}); one(std::integral_constant<int, 1>{});
+    };
+    f32x16_t sc[2];
+#pragma unroll
+    for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) sc[kb][r] = 0.f;
+    auto multiply_k = [&](int n, const raw_u32x4_t (&f)[2]) {
+      const int kb = n >> 1, ds = 2 * (n & 1);
+      sc[kb] = Cvt<Tag>::mfma32(make_uint4(f[0].x, f[0].y, f[0].z, f[0].w), qf[ds], sc[kb]);
+      sc[kb] = Cvt<Tag>::mfma32(make_uint4(f[1].x, f[1].y, f[1].z, f[1].w), qf[ds + 1], sc[kb]);
+    };
+    auto multiply_v = [&](int m, const raw_u32x4_t (&f)[2]) {
+#pragma unroll
+      for (int db = 0; db < 2; ++db) o[db] = Cvt<Tag>::mfma32(make_uint4(f[db].x, f[db].y, f[db].z, f[db].w), P[m], o[db]);
+    };
+    float psum = 0.f;
+    uint4 Pn[4];
+    float e[8];
+    auto exp_part = [&](int c, int part) {                     // 4 of the 32 scores of this lane: key block c >> 1, chunk c & 1, half `part`
+      const int kb = c >> 1, h = c & 1;
+#pragma unroll
+      for (int r = part * 4; r < part * 4 + 4; ++r) { e[r] = fast_exp2(fmaf(sc[kb][h * 8 + r], p.scale_log2e, -m_run)); psum += e[r]; }
+      if (part) Pn[c] = pack_chunk<Tag>(e);
+    };
+    auto exp_chunk = [&](int c) { exp_part(c, 0); exp_part(c, 1); };
+    auto beside = [&](auto valu_tag) {                         // two MFMAs beside VALU vector instructions each
+#if TT_ATTN_PIPE_SGB
+      constexpr int VALU = decltype(valu_tag)::value;
+      __builtin_amdgcn_sched_group_barrier(0x008, 1, 0); __builtin_amdgcn_sched_group_barrier(0x002, VALU, 0);
+      __builtin_amdgcn_sched_group_barrier(0x008, 1, 0); __builtin_amdgcn_sched_group_barrier(0x002, VALU, 0);
+#endif
+    };
+    request_k(std::integral_constant<int, 0>{}, x);
+    request_k(std::integral_constant<int, 1>{}, y);
+    lds_wait<2>(); multiply_k(0, x); __builtin_amdgcn_sched_barrier(0);
+    request_k(std::integral_constant<int, 2>{}, x);
+    lds_wait<2>(); multiply_k(1, y); __builtin_amdgcn_sched_barrier(0);
+    request_k(std::integral_constant<int, 3>{}, y);
+    lds_wait<2>(); multiply_k(2, x); exp_chunk(0); beside(std::integral_constant<int, 14>{}); __builtin_amdgcn_sched_barrier(0);
+    if constexpr (HAS_PV) request_v(std::integral_constant<int, 0>{}, x);
+    if constexpr (HAS_PV) lds_wait<4>(); else lds_wait<0>();
+    multiply_k(3, y); exp_chunk(1); beside(std::integral_constant<int, 14>{}); __builtin_amdgcn_sched_barrier(0);
+    if constexpr (HAS_PV) {
+      request_v(std::integral_constant<int, 1>{}, y);
+      lds_wait<4>(); multiply_v(0, x); exp_part(2, 0); beside(std::integral_constant<int, 7>{}); __builtin_amdgcn_sched_barrier(0);
+      request_v(std::integral_constant<int, 2>{}, x);
+      lds_wait<4>(); multiply_v(1, y); exp_part(2, 1); beside(std::integral_constant<int, 7>{}); __builtin_amdgcn_sched_barrier(0);
+      request_v(std::integral_constant<int, 3>{}, y);
+      lds_wait<4>(); multiply_v(2, x); exp_part(3, 0); beside(std::integral_constant<int, 7>{}); __builtin_amdgcn_sched_barrier(0);
+      lds_wait<0>(); multiply_v(3, y); exp_part(3, 1); beside(std::integral_constant<int, 7>{}); __builtin_amdgcn_sched_barrier(0);
+    } else {
+      exp_chunk(2); exp_chunk(3);
+    }
+    if (__any(!(psum <= PSUM_OK))) {                            // the tile outgrew the reference (always on the first tile): attn_kernel's slow path
+      float mx = sc[0][0];
+#pragma unroll
+      for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) mx = fmaxf(mx, sc[kb][r]);
+      mx = fmaxf(mx, __shfl_xor(mx, 32));
+      const float m_new = fmaxf(m_run, mx * p.scale_log2e);
+      const float alpha = fast_exp2(m_run - m_new);
+      l_run *= alpha;
+#pragma unroll
+      for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) o[i][r] *= alpha;
+      m_run = m_new;
+      psum = 0.f;
+      exp_chunk(0); exp_chunk(1); exp_chunk(2); exp_chunk(3);
+    }
+    l_run += psum;
+#pragma unroll
+    for (int c = 0; c < 4; ++c) P[c] = Pn[c];
+  };
+  typedef std::integral_constant<int, 0> B0;
+  typedef std::integral_constant<int, 1> B1;
+
+  stage_k(0, 0);
+  tile(0, B0{}, std::false_type{});
+  {
+    int t = 1;
+    for (; t + 1 < nt; t += 2) {
+      tile(t, B1{}, std::true_type{});
+      tile(t + 1, B0{}, std::true_type{});
+    }
+    if (t < nt) tile(t, B1{}, std::true_type{});
+  }
+  // ---- epilogue: O += V(nt-1) P(nt-1)
+  auto final_pv = [&](auto buf_tag) {
+    constexpr int BUF = decltype(buf_tag)::value;
+    constexpr int VOFF = 2 * K_BYTES + BUF * V_BYTES;
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    raw_u32x2_t g[16];
+    auto one = [&](auto n_tag) {                                // fragment n = 2 k + db
+      constexpr int N = decltype(n_tag)::value, k = N >> 1, db = N & 1, kb = k / 2, h = k % 2;
+      constexpr int off = VOFF + kb * 4096 + h * 1024 + ((db ^ h) << 6);
+      g[2 * N] = lds_read8_tr_off<off>(vr_addr[0]);
+      g[2 * N + 1] = lds_read8_tr_off<off>(vr_addr[1]);
+    };
+    one(std::integral_constant<int, 0>{}); one(std::integral_constant<int, 1>{}); one(std::integral_constant<int, 2>{}); one(std::integral_constant<int, 3>{});
+    one(std::integral_constant<int, 4>{}); one(std::integral_constant<int, 5>{}); one(std::integral_constant<int, 6>{}); one(std::integral_constant<int, 7>{});
+    lds_wait<0>();
+#pragma unroll
+    for (int n = 0; n < 8; ++n) {
+      const int k = n >> 1, db = n & 1;
+      o[db] = Cvt<Tag>::mfma32(make_uint4(g[2 * n].x, g[2 * n].y, g[2 * n + 1].x, g[2 * n + 1].y), P[k], o[db]);
+    }
+    __builtin_amdgcn_sched_barrier(0);
+  };
+  if ((nt - 1) & 1) final_pv(B1{}); else final_pv(B0{});
+
+  // ---- finalize (attn_kernel's: the wave's 32 x 64 outputs leave through a private LDS strip as whole rows)
+  const float l_tot = l_run + __shfl_xor(l_run, 32);
+  const float inv = l_tot > 0.f ? 1.0f / l_tot : 0.f;
+  __syncthreads();
+  constexpr int ROWB_O = D * ES, CPR_O = ROWB_O / 16;
+  char* strip = smem + wid * (32 * ROWB_O);
+#pragma unroll
+  for (int db = 0; db < 2; ++db)
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+      const int byte = (db * 32 + 8 * g + 4 * hi) * ES;
+      const float v4[4] = {o[db][g * 4] * inv, o[db][g * 4 + 1] * inv, o[db][g * 4 + 2] * inv, o[db][g * 4 + 3] * inv};
+      *(quad_t*)(strip + l31 * ROWB_O + (((byte >> 4) ^ (l31 & (CPR_O - 1))) << 4) + (byte & 15)) = f32_to_quad<Tag>(v4);
+    }
+  constexpr int RPP = 64 / CPR_O;
+  const int oc = lane % CPR_O, orow = lane / CPR_O;
+#pragma unroll
+  for (int pass = 0; pass < 32 / RPP; ++pass) {
+    const int r = pass * RPP + orow;
+    const uint4 v = *(const uint4*)(strip + r * ROWB_O + ((oc ^ (r & (CPR_O - 1))) << 4));
+    const int qr = blk.x * QB + wid * 32 + r;
+    if (qr < p.lq) *(uint4*)(p.out + (((long)seq * p.lq + qr) * p.ldo + head * D) * ES + oc * 16) = v;
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
 // fp8 spatial self-attention (BASELINE config 5): Q, K, V^T arrive as OCP e4m3 bytes (tt_gemm out_fp8), both products run
 // on v_mfma_scale_f32_32x32x64_f8f6f4 with unit block scales (E8M0 0x7f) -- the K = 64 form issues at twice the bf16 rate
 // (tools/mfma_f8f6f4_probe.hip: 4 515 TFLOP/s against 1 745 for v_mfma_f32_32x32x16_fp8_fp8, which runs at the bf16 rate; layout
@@ -881,6 +1138,14 @@ void launch_attn(const AttnP& p, hipStream_t st) {
   if constexpr (D == 64 && Elem<Tag>::ES == 2) {
     if (p.v_rows) {                                          // row-major V (mask 0, checked by tt_attention)
       constexpr size_t lds = 2 * (KB * D * 2 + D * KB * 2);
+      static int pipe = -1;                                  // TT_ATTN_PIPE=0: attn_kernel for every key count (A/B)
+      if (pipe < 0) { const char* e = getenv("TT_ATTN_PIPE"); pipe = e ? atoi(e) : 1; }
+      if (pipe && p.lk >= 2 * KB && p.lk % KB == 0) {        // whole key tiles: the software-pipelined kernel
+        static unsigned long long attr_done_p = 0;
+        tt_lds_opt_in((const void*)attn_pipe_kernel<Tag>, (int)lds, &attr_done_p);
+        hipLaunchKernelGGL((attn_pipe_kernel<Tag>), dim3((p.lq + QB - 1) / QB, p.heads, p.nseq), dim3(256), lds, st, p);
+        return;
+      }
       static unsigned long long attr_done = 0;
       tt_lds_opt_in((const void*)attn_kernel<Tag, 64, 0, false, true>, (int)lds, &attr_done);
       hipLaunchKernelGGL((attn_kernel<Tag, 64, 0, false, true>), dim3((p.lq + QB - 1) / QB, p.heads, p.nseq), dim3(256), lds, st, p);
