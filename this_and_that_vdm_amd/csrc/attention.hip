@@ -610,7 +610,11 @@ __global__ __launch_bounds__(256, (D == 64 && Elem<Tag>::ES == 2) ? 2 : 1) void 
 // path rescales O after the iteration's PV: O and P(t-1) are both relative to the old reference at that point).  Same MFMA operands and summation
 // order as attn_kernel: bit-identical outputs (tests/test_ops_gpu.py).  (A deeper version -- S(t+1) beside the softmax as well, two S and two P
 // register sets alternating with the tile parity -- compiled to 64-register tuple copies per tile and 236-260 bytes of scratch per lane at two
-// waves per SIMD, and to accumulator-file copies of every score at one: not kept.)
+// waves per SIMD, and to accumulator-file copies of every score at one: not kept.  Also measured on this kernel, one call, 1 792 / 7 168 keys:
+// s_setprio(1) around the interleaved phases 125.6 -> 124.8 / 1 816 -> 1 808 us; without the sched_group_barrier hints 126.0 / 1 816: the
+// compiler's own order is the same.  Per wave and tile the loop now takes ~510 ns against ~580 for attn_kernel; 32 quarter-rate exponentials
+// + 32 fma + 32 add + 16 conversions + 16 MFMA issue slots are ~900 issue clocks = ~470-490 ns at the clock the kernel runs at: what is
+// left is the vector instruction count itself.)
 template <typename Tag>
 __global__ __launch_bounds__(256, 2) void attn_pipe_kernel(const AttnP p) {
   static_assert(Elem<Tag>::ES == 2, "16-bit storage");

@@ -318,7 +318,12 @@ def attention(q, k, vt, out, *, nseq, lq, heads, head_dim, mask, lk, k_seq_strid
     _wrote(out)
     if ev is not None:
         tag = _TAG[a.dtype]
-        kname = f"attn8_kernel<{tag}, {head_dim}>" if fp8 else f"attn_kernel<{tag}, {head_dim}, {mask}{', true' if qx is not None else ''}{', false, true' if v_rows else ''}>"
+        if fp8:
+            kname = f"attn8_kernel<{tag}, {head_dim}>"
+        elif v_rows and lk >= 128 and lk % 64 == 0 and os.environ.get("TT_ATTN_PIPE", "1") != "0":     # (launch_attn in attention.hip)
+            kname = f"attn_pipe_kernel<{tag}>"
+        else:
+            kname = f"attn_kernel<{tag}, {head_dim}, {mask}{', true' if qx is not None else ''}{', false, true' if v_rows else ''}>"
         flops = 4.0 * nseq * heads * lq * lk * head_dim + (2.0 * nseq * lq * heads * head_dim * qx.shape[1] if qx is not None else 0.0)
         _prof_end(ev, kname, flops, shape=("attn", nseq * heads, lq, lk, mask, 0))
     return out

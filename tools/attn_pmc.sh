@@ -5,7 +5,7 @@ set -u
 out=${1:-gpurun_out/attn_pmc}; mkdir -p $out
 cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
 timeout 300 rocprofv3 --pmc SQ_WAVE_CYCLES SQ_BUSY_CU_CYCLES SQ_INSTS_VALU SQ_INSTS_MFMA SQ_VALU_MFMA_BUSY_CYCLES SQ_ACTIVE_INST_VALU SQ_WAIT_INST_ANY SQ_WAIT_ANY \
-  --kernel-trace --kernel-include-regex "attn_kernel|attn8_kernel" --output-format csv -d $out/raw -o p -- python tools/attn_bench.py > $out/run.log 2>&1
+  --kernel-trace --kernel-include-regex "attn_kernel|attn_pipe_kernel|attn8_kernel" --output-format csv -d $out/raw -o p -- python tools/attn_bench.py > $out/run.log 2>&1
 python - "$out" <<'PY'
 import csv, glob, sys, collections, os
 out = sys.argv[1]

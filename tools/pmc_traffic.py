@@ -15,7 +15,7 @@ def per_kernel(d, counter):
         for r in csv.DictReader(open(f)):
             if r["Counter_Name"] != counter:
                 continue
-            m = re.search(r"(gemm_pp_kernel|gemm_w320h_kernel|gemm_w320_kernel|gemm_kernel|attn_kernel|attn8_kernel|tattn_kernel|splitk_epilogue_kernel)<[^>]*>", r["Kernel_Name"])
+            m = re.search(r"(gemm_pp_kernel|gemm_w320h_kernel|gemm_w320_kernel|gemm_kernel|attn_kernel|attn_pipe_kernel|attn8_kernel|tattn_kernel|splitk_epilogue_kernel)<[^>]*>", r["Kernel_Name"])
             if not m:
                 continue
             a = acc[m.group(0)]

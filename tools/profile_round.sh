@@ -17,7 +17,7 @@ python tools/trace_agg.py "$(find $out/stats -name '*kernel_trace.csv' | head -1
 tail -1 $out/stats.log | cut -c1-160
 if [ "$res" = "lo" ] && [ -z "$extra" ]; then
   for c in FETCH_SIZE WRITE_SIZE; do
-    timeout 500 rocprofv3 --pmc $c --kernel-trace --kernel-include-regex "gemm_kernel|gemm_pp_kernel|gemm_w320_kernel|gemm_w320h_kernel|attn_kernel|attn8_kernel" --output-format csv -d $out/$c -o p -- \
+    timeout 500 rocprofv3 --pmc $c --kernel-trace --kernel-include-regex "gemm_kernel|gemm_pp_kernel|gemm_w320_kernel|gemm_w320h_kernel|attn_kernel|attn_pipe_kernel|attn8_kernel" --output-format csv -d $out/$c -o p -- \
       python tools/pmc_step.py vgl lo > $out/$c.log 2>&1 || echo "pmc pass $c failed"
   done
   python tools/pmc_traffic.py $out/FETCH_SIZE $out/WRITE_SIZE vgl_lo gpurun_out/profiles/r6_hbm_traffic.json gpurun_out/profiles/r6_vgl_lo_pmc_fetch_write_raw.json | head -24
