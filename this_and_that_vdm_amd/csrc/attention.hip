@@ -612,9 +612,11 @@ __global__ __launch_bounds__(256, (D == 64 && Elem<Tag>::ES == 2) ? 2 : 1) void 
 // register sets alternating with the tile parity -- compiled to 64-register tuple copies per tile and 236-260 bytes of scratch per lane at two
 // waves per SIMD, and to accumulator-file copies of every score at one: not kept.  Also measured on this kernel, one call, 1 792 / 7 168 keys:
 // s_setprio(1) around the interleaved phases 125.6 -> 124.8 / 1 816 -> 1 808 us; without the sched_group_barrier hints 126.0 / 1 816: the
-// compiler's own order is the same.  Per wave and tile the loop now takes ~510 ns against ~580 for attn_kernel; 32 quarter-rate exponentials
-// + 32 fma + 32 add + 16 conversions + 16 MFMA issue slots are ~900 issue clocks = ~470-490 ns at the clock the kernel runs at: what is
-// left is the vector instruction count itself.)
+// compiler's own order is the same.  Per wave and tile the loop now takes ~510 ns against ~580 for attn_kernel.  Ablation builds (timing only,
+// 7 168 keys, 1 826 us as built): no exponentials 1 537, no row-sum adds 1 695, NO MFMAs 732 us -- the vector / LDS skeleton is 732 us and the
+// sixteen MFMAs of a tile still add most of their own time: a SIMD hides ~5 single-issue instructions beside one 32 x 32 x 16 MFMA
+// (MI355X_MICROARCH.md), a d = 64 tile has 112 of them for 16 MFMAs, and the first key block's chain has no softmax work to sit beside.
+// DESIGN.md 6.R6 has the floor this implies.)
 template <typename Tag>
 __global__ __launch_bounds__(256, 2) void attn_pipe_kernel(const AttnP p) {
   static_assert(Elem<Tag>::ES == 2, "16-bit storage");
