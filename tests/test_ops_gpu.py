@@ -381,6 +381,34 @@ def test_attention_pipelined_self_attention(ops, dtype, l, growth, monkeypatch):
     assert torch.equal(out_r, out_t), "the pipelined kernel must give the un-pipelined kernel's output bit for bit"
 
 
+def test_attention_pipe_switch_off_gives_the_same_bits(ops):
+    """TT_ATTN_PIPE=0 (read once per process) keeps attn_kernel for every key count: a child process with the switch off must produce the
+    bytes this process gets from attn_pipe_kernel (same seeded inputs; 448 keys = 7 tiles, a ragged query block)."""
+    import hashlib
+    import os
+    import subprocess
+    import sys
+    code = r"""
+import hashlib, sys, torch
+sys.path.insert(0, %r)
+from this_and_that_vdm_amd import ops
+g = torch.Generator().manual_seed(7)
+nseq, l, heads, d = 2, 448, 3, 64
+c = heads * d
+qkv = (torch.randn(nseq * l, 3 * c, generator=g) * 1.5).to(torch.bfloat16).cuda()
+out = torch.empty(nseq * l, c, dtype=torch.bfloat16, device="cuda")
+ops.attention(qkv[:, :c], qkv[:, c:2 * c], qkv[:, 2 * c:], out, nseq=nseq, lq=l, heads=heads, head_dim=d, mask=0, lk=l, k_seq_stride=l, v_seq_stride=l, v_rows=True)
+torch.cuda.synchronize()
+print("HASH", hashlib.sha256(out.cpu().view(torch.int16).numpy().tobytes()).hexdigest())
+""" % os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    hashes = []
+    for pipe in ("1", "0"):
+        r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, env=dict(os.environ, TT_ATTN_PIPE=pipe), timeout=600)
+        assert r.returncode == 0, r.stderr[-2000:]
+        hashes.append([ln.split()[1] for ln in r.stdout.splitlines() if ln.startswith("HASH")][0])
+    assert hashes[0] == hashes[1]
+
+
 @pytest.mark.parametrize("dtype", DTYPES)
 @pytest.mark.parametrize("s", [1, 5, 78])
 def test_attention_cross_spatial_and_temporal(ops, dtype, s):
