@@ -50,7 +50,11 @@ print(json.dumps(out), flush=True)
 def test_one_rank_rccl_group_runs_the_collectives_of_the_n_gpu_path():
     if not torch.cuda.is_available():
         pytest.skip("needs a GPU")
-    env = dict(os.environ, TT_REPO=REPO, HSA_ENABLE_IPC_MODE_LEGACY="0", MASTER_ADDR="127.0.0.1", MASTER_PORT="29631")
+    import socket
+    with socket.socket() as sk:                               # a free rendezvous port (the suite may share the host with other jobs)
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    env = dict(os.environ, TT_REPO=REPO, HSA_ENABLE_IPC_MODE_LEGACY="0", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
     r = subprocess.run([sys.executable, "-c", CHILD], capture_output=True, text=True, env=env, timeout=600)
     assert r.returncode == 0, r.stderr[-3000:]
     d = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
